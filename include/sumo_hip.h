@@ -1,0 +1,63 @@
+/* sumo_hip.h -- C ABI of the MI355X-native batched RoboSumo environment engine (libsumo_hip.so).
+ *
+ * This is the drop-in boundary for the vectorised env step.  The reference has no FFI for this path -- its
+ * seam is the Python VecEnv interface -- so each entry point names the reference interface it stands in for:
+ *
+ *   sumo_create   load_model_from_path + MjSim construction for every worker process
+ *                 (reference robosumo/robosumo/envs/mujoco_env.py:55-57, subproc_vec_env.py:49-56)
+ *   sumo_reset    SubprocVecEnv.reset -> env.reset() in each worker
+ *                 (reference subproc_vec_env.py:78-82, mujoco_env.py:104-108, sumo.py:232-253)
+ *   sumo_step     SubprocVecEnv.step_async/step_wait -> worker 'step' incl. auto-reset
+ *                 (reference subproc_vec_env.py:10-16,65-76; sumo_env.py:40-72; sumo.py:120-192;
+ *                  mujoco_env.py:125-129 -> mj_step x frame_skip, mujoco-py/mujoco_py/mjsim.pyx:115-129)
+ *   sumo_get_state / sumo_set_state   MjSim.get_state / set_state (mujoco-py/mujoco_py/mjsim.pyx:247-276)
+ *
+ * All array arguments of sumo_reset / sumo_step are DEVICE pointers owned by the caller (obs, rewards and
+ * dones never leave HBM); sumo_get_state / sumo_set_state take HOST pointers and synchronise.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Every function returns 0 on success and a negative
+ * code on error; sumo_last_error() then describes it.  A handle is bound to one GPU; calls on one handle are
+ * not re-entrant.
+ *
+ * Shapes (E = num_envs, A = 2 agents, row-major):
+ *   actions  float32 [E][A][act_stride]     raw policy outputs (clamped to ctrlrange inside, as MuJoCo does)
+ *   obs      float32 [E][A][obs_stride]     agents.py:190-214 layout + time feature (sumo_env.py:68-70)
+ *   info     float64 [E][A][8]              ctrl, lose, win, main, move, push, shaping, flags(bit0 winner, bit1 timeout)
+ *   done     uint8   [E][A]
+ *   ep_r, ep_dr float64 [E]; ep_l int32 [E] episode return / dense return / length of agent 0, valid where done
+ */
+#ifndef SUMO_HIP_H
+#define SUMO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sumo_engine* sumo_handle_t;
+
+#define SUMO_INFO_STRIDE 8
+#define SUMO_NDIMS 16 /* nq nv nu nbody njnt ngeom npair nagent obs_stride act_stride maxcon maxefc lds_bytes state_stride 0 0 */
+
+const char* sumo_last_error(void);
+int sumo_create(const void* model_blob, size_t nbytes, int num_envs, int device, sumo_handle_t* out);
+int sumo_destroy(sumo_handle_t h);
+int sumo_dims(sumo_handle_t h, int32_t* out /* [SUMO_NDIMS] */);
+int sumo_reset(sumo_handle_t h, const uint64_t* seeds_host /* [E] or NULL */, const uint8_t* mask_dev /* [E] or NULL */,
+               float* obs_dev, void* stream);
+int sumo_step(sumo_handle_t h, const float* actions_dev, float* obs_dev, double* info_dev, uint8_t* done_dev,
+              double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream);
+int sumo_get_state(sumo_handle_t h, double* qpos, double* qvel, double* warm, int32_t* counters /* [E][2] */);
+int sumo_set_state(sumo_handle_t h, const double* qpos, const double* qvel, const double* warm,
+                   const int32_t* counters);
+/* debug / parity hook: run mj_forward once per env at its current state with ctrl (HOST float64 [E][nu]) and return
+ * qacc (HOST float64 [E][nv]) plus per-env {ncon, nefc, newton iterations, dropped contacts} (HOST int32 [E][4]). */
+int sumo_debug_forward(sumo_handle_t h, const double* ctrl, double* qacc, int32_t* counts);
+/* device-side statistics accumulated since creation: forward calls, newton iterations, contacts, efc rows,
+ * max ncon, max nefc, max newton iterations, dropped contacts (HOST float64 [8]). */
+int sumo_stats(sumo_handle_t h, double* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

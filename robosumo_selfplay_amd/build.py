@@ -1,0 +1,52 @@
+"""Build the in-tree HIP libraries for gfx950 (hipcc cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+ARCH = "gfx950"
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: cannot build the HIP engine")
+    return exe
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def lib_path(name):
+    return os.path.join(_CSRC, name)
+
+
+def build_all(force=False, verbose=False):
+    """Compile every HIP translation unit into its shared library. Returns the list of built paths."""
+    inc = os.path.join(os.path.dirname(_CSRC), "..", "include")
+    jobs = [
+        ("libsumo_hip.so", ["sumo_engine.hip"]),
+        ("libsumo_ppo.so", ["ppo_kernels.hip"]),
+    ]
+    out = []
+    for target, srcs in jobs:
+        srcs = [os.path.join(_CSRC, s) for s in srcs]
+        if not all(os.path.exists(s) for s in srcs):
+            continue
+        tpath = os.path.join(_CSRC, target)
+        deps = srcs + [os.path.join(inc, h) for h in os.listdir(inc)]
+        if force or _stale(tpath, deps):
+            cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-I", inc, "-o", tpath] + srcs
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        out.append(tpath)
+    return out
+
+
+if __name__ == "__main__":
+    print("\n".join(build_all(force=True, verbose=True)))

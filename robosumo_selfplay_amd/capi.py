@@ -1,0 +1,132 @@
+"""ctypes binding of the engine's C ABI (include/sumo_hip.h -> csrc/libsumo_hip.so).
+
+This is the stub a maintainer of the reference would drop in next to subproc_vec_env.py.
+There is NO CPU fallback: if the library is missing or no GPU is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+INFO_STRIDE = 8
+NDIMS = 16
+_LIB = None
+
+
+class SumoHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = _build.lib_path("libsumo_hip.so")
+        if not os.path.exists(path):
+            raise SumoHipError("%s not found: build it with `python -m robosumo_selfplay_amd.build` "
+                               "(the HIP engine has no CPU fallback)" % path)
+        L = C.CDLL(path)
+        L.sumo_last_error.restype = C.c_char_p
+        vp, i32 = C.c_void_p, C.c_int
+        L.sumo_create.argtypes = [vp, C.c_size_t, i32, i32, C.POINTER(vp)]
+        L.sumo_destroy.argtypes = [vp]
+        L.sumo_dims.argtypes = [vp, vp]
+        L.sumo_reset.argtypes = [vp, vp, vp, vp, vp]
+        L.sumo_step.argtypes = [vp] * 9
+        L.sumo_get_state.argtypes = [vp] * 5
+        L.sumo_set_state.argtypes = [vp] * 5
+        L.sumo_debug_forward.argtypes = [vp] * 4
+        L.sumo_stats.argtypes = [vp, vp]
+        for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_get_state",
+                  "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
+            getattr(L, n).restype = i32
+        _LIB = L
+    return _LIB
+
+
+EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step",
+           "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats")
+
+
+def _np(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _chk(rc):
+    if rc != 0:
+        raise SumoHipError("sumo_hip error %d: %s" % (rc, lib().sumo_last_error().decode()))
+
+
+class Engine:
+    """Thin owner of one ``sumo_handle_t``; device buffers are passed as raw pointers (ints)."""
+
+    def __init__(self, model, num_envs, device=0):
+        L = lib()
+        blob = model.to_blob()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        h = C.c_void_p()
+        _chk(L.sumo_create(C.cast(buf, C.c_void_p), len(blob), int(num_envs), int(device), C.byref(h)))
+        self.h = h
+        self.N = int(num_envs)
+        d = np.zeros(NDIMS, np.int32)
+        _chk(L.sumo_dims(self.h, _np(d)))
+        (self.nq, self.nv, self.nu, self.nbody, self.njnt, self.ngeom, self.npair, self.nagent, self.obs_stride,
+         self.act_stride, self.maxcon, self.maxefc, self.lds_bytes, self.state_stride) = [int(x) for x in d[:14]]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sumo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, obs_ptr, seeds=None, mask_ptr=None, stream=None):
+        s = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
+        if s is not None and s.shape != (self.N,):
+            raise ValueError("seeds must have shape (%d,)" % self.N)
+        _chk(lib().sumo_reset(self.h, _np(s), mask_ptr, obs_ptr, stream))
+
+    def step(self, actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream=None):
+        _chk(lib().sumo_step(self.h, actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream))
+
+    def get_state(self):
+        qpos = np.zeros((self.N, self.nq))
+        qvel = np.zeros((self.N, self.nv))
+        warm = np.zeros((self.N, self.nv))
+        cnt = np.zeros((self.N, 2), np.int32)
+        _chk(lib().sumo_get_state(self.h, _np(qpos), _np(qvel), _np(warm), _np(cnt)))
+        return qpos, qvel, warm, cnt
+
+    def set_state(self, qpos=None, qvel=None, warm=None, counters=None):
+        def f(a, dt, shape):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            if a.shape != shape:
+                raise ValueError("bad shape %s, expected %s" % (a.shape, shape))
+            return a
+        qpos = f(qpos, np.float64, (self.N, self.nq))
+        qvel = f(qvel, np.float64, (self.N, self.nv))
+        warm = f(warm, np.float64, (self.N, self.nv))
+        counters = f(counters, np.int32, (self.N, 2))
+        _chk(lib().sumo_set_state(self.h, _np(qpos), _np(qvel), _np(warm), _np(counters)))
+
+    def debug_forward(self, ctrl):
+        ctrl = np.ascontiguousarray(ctrl, np.float64)
+        if ctrl.shape != (self.N, self.nu):
+            raise ValueError("ctrl must have shape (%d, %d)" % (self.N, self.nu))
+        qacc = np.zeros((self.N, self.nv))
+        counts = np.zeros((self.N, 4), np.int32)
+        _chk(lib().sumo_debug_forward(self.h, _np(ctrl), _np(qacc), _np(counts)))
+        return qacc, counts
+
+    def stats(self):
+        o = np.zeros(8)
+        _chk(lib().sumo_stats(self.h, _np(o)))
+        return dict(forward=o[0], newton=o[1], contacts=o[2], efc=o[3], max_ncon=o[4], max_nefc=o[5],
+                    max_newton=o[6], dropped=o[7])

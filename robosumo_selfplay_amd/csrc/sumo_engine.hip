@@ -1,0 +1,1672 @@
+// sumo_engine.hip -- MI355X (gfx950) batched RoboSumo environment engine: kernels + C ABI (include/sumo_hip.h).
+//
+// One environment per 64-lane wavefront (one wave per workgroup).  The whole env step -- frame_skip x RK4 x
+// forward dynamics (kinematics, CoM/CRB mass matrix, collision, pyramidal contact + joint-limit rows, bias forces,
+// primal Newton solve), game rules, rewards, done, auto-reset with a counter RNG, observation write -- runs in ONE
+// launch; per-env state (qpos, qvel, warm start) is read from / written to HBM once per env step as a contiguous
+// record, everything else lives in LDS.  float64 throughout (the reference's mjtNum is double,
+// mujoco-py/mujoco_py/pxd/mjmodel.pxd:81).
+//
+// Reference behaviour being reproduced (file:line are in the reference checkout):
+//   env step + auto-reset     subproc_vec_env.py:10-16, sumo_env.py:40-72, robosumo/robosumo/envs/sumo.py:120-202
+//   observation               robosumo/robosumo/envs/agents.py:190-214
+//   reset                     robosumo/robosumo/envs/sumo.py:232-253, mujoco_env.py:104-119
+//   physics                   mujoco_env.py:125-129 -> mjsim.pyx:115-129 -> mj_step (MuJoCo 2.1)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/sumo_hip.h"
+#include "../../include/sumo_model.h"
+
+#define WAVE 64
+#define MINVAL 1e-15
+#define MAXCHAIN 8   /* dofs on the path root -> body (free joint 6 + hip + ankle) */
+#define MAXBCHAIN 4  /* bodies on the path root -> body */
+#define PI_D 3.14159265358979323846
+#define SEGBOX_BISECT 32
+#define RNG_NORMAL_BASE 64
+
+// ---------------------------------------------------------------------------------------------------------
+// device-side model view
+// ---------------------------------------------------------------------------------------------------------
+struct Aux {  // derived integer tables (built on the host in build_aux)
+  const int* ai;
+  const double* af;
+  const signed char* pic;  // pos_in_chain[nbody][nv]: slot of dof in the body's chain, -1 if absent
+  int ndepth;              // levels 0..ndepth-1 (world = level 0)
+  int ntri;                // nv*(nv+1)/2
+  int o_lvl_adr, o_lvl_body, o_child_adr, o_child, o_chain_len, o_chain, o_bchain_len, o_bchain, o_body_agent,
+      o_tri_i, o_tri_j;
+  int o_wgmat;  // double table: 9 per geom (valid for world geoms)
+};
+
+struct Layout {  // LDS offsets in doubles unless noted
+  int ld;        // leading dimension of M / H (odd)
+  int maxcon, maxefc, maxcand;
+  int qpos, qvel, warm, ctrl, x0, accv, acca, tmpv;
+  int xpos, xquat, xipos, gaxis, xanchor, xaxis, com, cinert, cdof, abuf, cfrc;  // "kin scratch"
+  int H;                                                                           // aliases kin scratch
+  int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim;
+  int cond, Jb, cpar, cW, cp, jar, Jv, D, aref;
+  int i_base;  // start of int region (in doubles)
+  // int region offsets (in ints, relative to int base)
+  int con_b, dofidx, plist, lim_dof, lim_sign, scal;
+  int b_slotof;  // byte offset (relative to int base, in bytes)
+  int total_bytes;
+};
+
+struct StepArgs {
+  double* state;       // [N][state_stride]
+  int* counters;       // [N][4] num_steps, reset_count, -, -
+  uint64_t* seeds;     // [N]
+  int state_stride;
+  const float* actions;
+  float* obs;
+  double* info;
+  uint8_t* done;
+  double* ep_r;
+  double* ep_dr;
+  int* ep_l;
+  const uint8_t* mask;  // reset only
+  unsigned long long* stats;
+  int obs_stride, act_stride;
+  int N;
+  // debug forward
+  const double* dbg_ctrl;
+  double* dbg_qacc;
+  int* dbg_counts;
+};
+
+#define MI(name) (mdl.ibase + mdl.o_##name)
+#define MF(name) (mdl.fbase + mdl.o_##name)
+#define AI(name) (aux.ai + aux.o_##name)
+
+#define SYNC() __syncthreads()
+
+// ---------------------------------------------------------------------------------------------------------
+// small math
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ double normalize3(double* v) {
+  double n = sqrt(dot3(v, v));
+  if (n < MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; } else { v[0] /= n; v[1] /= n; v[2] /= n; }
+  return n;
+}
+__device__ __forceinline__ void normalize4(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
+}
+__device__ __forceinline__ void mulquat(double* r, const double* a, const double* b) {
+  double t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double t3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
+}
+__device__ __forceinline__ void quat2mat(double* m, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ void mulmatvec3(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+         z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void mulmatTvec3(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2],
+         z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void axisangle2quat(double* q, const double* axis, double angle) {
+  double s = sin(angle * 0.5);
+  q[0] = cos(angle * 0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+__device__ __forceinline__ double dot6(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+__device__ __forceinline__ void mul_inert_vec(double* r, const double* i, const double* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+__device__ __forceinline__ void cross_motion(double* r, const double* vel, const double* v) {
+  r[0] = -vel[2] * v[1] + vel[1] * v[2];
+  r[1] = vel[2] * v[0] - vel[0] * v[2];
+  r[2] = -vel[1] * v[0] + vel[0] * v[1];
+  r[3] = -vel[2] * v[4] + vel[1] * v[5] - vel[5] * v[1] + vel[4] * v[2];
+  r[4] = vel[2] * v[3] - vel[0] * v[5] + vel[5] * v[0] - vel[3] * v[2];
+  r[5] = -vel[1] * v[3] + vel[0] * v[4] - vel[4] * v[0] + vel[3] * v[1];
+}
+__device__ __forceinline__ void cross_force(double* r, const double* vel, const double* f) {
+  r[0] = -vel[2] * f[1] + vel[1] * f[2] - vel[5] * f[4] + vel[4] * f[5];
+  r[1] = vel[2] * f[0] - vel[0] * f[2] + vel[5] * f[3] - vel[3] * f[5];
+  r[2] = -vel[1] * f[0] + vel[0] * f[1] - vel[4] * f[3] + vel[3] * f[4];
+  r[3] = -vel[2] * f[4] + vel[1] * f[5];
+  r[4] = vel[2] * f[3] - vel[0] * f[5];
+  r[5] = -vel[1] * f[3] + vel[0] * f[4];
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    int t = __shfl_up(inc, o, WAVE);
+    if (lane >= o) inc += t;
+  }
+  *total = __shfl(inc, WAVE - 1, WAVE);
+  return inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// narrow phase primitives.  A lane produces up to 3 contacts {dist, pos, normal} in registers.
+// ---------------------------------------------------------------------------------------------------------
+struct Con1 { double dist, pos[3], nrm[3]; int ok; };
+
+__device__ __forceinline__ void sphere_sphere(Con1& c, double margin, const double* p1, double r1, const double* p2, double r2) {
+  double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  double cd2 = dot3(dif, dif), mind = margin + r1 + r2;
+  c.ok = 0;
+  if (cd2 > mind * mind) return;
+  double len = sqrt(cd2);
+  if (len < MINVAL) { dif[0] = 0; dif[1] = 0; dif[2] = 1; } else { dif[0] /= len; dif[1] /= len; dif[2] /= len; }
+  c.dist = len - r1 - r2;
+  for (int k = 0; k < 3; k++) { c.nrm[k] = dif[k]; c.pos[k] = p1[k] + dif[k] * (r1 + 0.5 * c.dist); }
+  c.ok = 1;
+}
+__device__ __forceinline__ void plane_sphere(Con1& c, double margin, const double* pp, const double* n, const double* sp, double r) {
+  double t[3] = {sp[0] - pp[0], sp[1] - pp[1], sp[2] - pp[2]};
+  double cd = dot3(t, n);
+  c.ok = 0;
+  if (cd > margin + r) return;
+  c.dist = cd - r;
+  for (int k = 0; k < 3; k++) { c.nrm[k] = n[k]; c.pos[k] = sp[k] - n[k] * (r + 0.5 * c.dist); }
+  c.ok = 1;
+}
+__device__ __forceinline__ void sphere_box(Con1& c, double margin, const double* sp, double r, const double* bp, const double* bm,
+                                           const double* bs) {
+  double t[3] = {sp[0] - bp[0], sp[1] - bp[1], sp[2] - bp[2]}, ctr[3], cl[3], dl[3];
+  mulmatTvec3(ctr, bm, t);
+  for (int k = 0; k < 3; k++) { cl[k] = ctr[k] > bs[k] ? bs[k] : (ctr[k] < -bs[k] ? -bs[k] : ctr[k]); dl[k] = cl[k] - ctr[k]; }
+  double dist = sqrt(dot3(dl, dl));
+  c.ok = 0;
+  if (dist - r > margin) return;
+  double nl[3], pl[3];
+  if (dist <= MINVAL) {
+    double best = 1e300; int kb = 0, sb = 1;
+    for (int k = 0; k < 3; k++)
+      for (int s = -1; s <= 1; s += 2) {
+        double fd = fabs(s * bs[k] - ctr[k]);
+        if (fd < best) { best = fd; kb = k; sb = s; }
+      }
+    nl[0] = nl[1] = nl[2] = 0;
+    if (kb == 0) nl[0] = -sb; else if (kb == 1) nl[1] = -sb; else nl[2] = -sb;
+    c.dist = -best - r;
+  } else {
+    for (int k = 0; k < 3; k++) nl[k] = dl[k] / dist;
+    c.dist = dist - r;
+  }
+  for (int k = 0; k < 3; k++) pl[k] = ctr[k] + nl[k] * (r + 0.5 * c.dist);
+  double pw[3];
+  mulmatvec3(c.nrm, bm, nl);
+  mulmatvec3(pw, bm, pl);
+  for (int k = 0; k < 3; k++) c.pos[k] = pw[k] + bp[k];
+  c.ok = 1;
+}
+__device__ __forceinline__ double seg_box_dgrad(const double* cc, const double* a, const double* bs, double t) {
+  double g = 0;
+  for (int k = 0; k < 3; k++) {
+    double p = cc[k] + t * a[k];
+    if (p > bs[k]) g += a[k] * (p - bs[k]);
+    else if (p < -bs[k]) g += a[k] * (p + bs[k]);
+  }
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the per-wave environment context
+// ---------------------------------------------------------------------------------------------------------
+struct Params { sumo_model_t mdl; Aux aux; Layout L; };  // lives in device memory; read through scalar loads
+
+struct Ctx {
+  const Params* P;
+  double* sm;    // LDS base (doubles)
+  int* si;       // LDS int region
+  unsigned char* sb;  // LDS byte region (slotof)
+  int lane;
+  // per-forward scalars (wave-uniform)
+  int ncon, nlim, nefc, ndropped;
+  // statistics accumulated over the launch
+  int st_forward, st_newton, st_ncon, st_nefc, st_maxcon, st_maxefc, st_maxnewton, st_dropped;
+};
+
+#define S(off) (c.sm + c.P->L.off)
+
+// ---- position / velocity stage --------------------------------------------------------------------------
+__device__ void kin_body(Ctx& c, int b) {
+  const sumo_model_t& mdl = c.P->mdl;
+  double* qpos = S(qpos);
+  int pid = MI(body_parentid)[b], ja = MI(body_jntadr)[b], jn = MI(body_jntnum)[b];
+  double xp[3], xq[4], R[9], v[3];
+  if (jn == 1 && MI(jnt_type)[ja] == SUMO_JNT_FREE) {
+    double* q = qpos + MI(jnt_qposadr)[ja];
+    double qq[4] = {q[3], q[4], q[5], q[6]};
+    normalize4(qq);
+    q[3] = qq[0]; q[4] = qq[1]; q[5] = qq[2]; q[6] = qq[3];  // in-place normalisation, as mj_kinematics
+    xp[0] = q[0]; xp[1] = q[1]; xp[2] = q[2];
+    xq[0] = qq[0]; xq[1] = qq[1]; xq[2] = qq[2]; xq[3] = qq[3];
+    for (int k = 0; k < 3; k++) S(xanchor)[3 * ja + k] = xp[k];
+  } else {
+    quat2mat(R, S(xquat) + 4 * pid);
+    mulmatvec3(v, R, MF(body_pos) + 3 * b);
+    for (int k = 0; k < 3; k++) xp[k] = S(xpos)[3 * pid + k] + v[k];
+    mulquat(xq, S(xquat) + 4 * pid, MF(body_quat) + 4 * b);
+    for (int j = ja; j < ja + jn; j++) {
+      double ql[4], anchor[3];
+      const double* jp = MF(jnt_pos) + 3 * j;
+      const double* jax = MF(jnt_axis) + 3 * j;
+      quat2mat(R, xq);
+      mulmatvec3(v, R, jp);
+      for (int k = 0; k < 3; k++) { anchor[k] = xp[k] + v[k]; S(xanchor)[3 * j + k] = anchor[k]; }
+      mulmatvec3(v, R, jax);
+      for (int k = 0; k < 3; k++) S(xaxis)[3 * j + k] = v[k];
+      int qa = MI(jnt_qposadr)[j];
+      axisangle2quat(ql, jax, qpos[qa] - MF(qpos0)[qa]);
+      mulquat(xq, xq, ql);
+      quat2mat(R, xq);
+      mulmatvec3(v, R, jp);
+      for (int k = 0; k < 3; k++) xp[k] = anchor[k] - v[k];
+    }
+    normalize4(xq);
+  }
+  for (int k = 0; k < 3; k++) S(xpos)[3 * b + k] = xp[k];
+  for (int k = 0; k < 4; k++) S(xquat)[4 * b + k] = xq[k];
+  quat2mat(R, xq);
+  mulmatvec3(v, R, MF(body_ipos) + 3 * b);
+  for (int k = 0; k < 3; k++) S(xipos)[3 * b + k] = xp[k] + v[k];
+  double qi[4];
+  mulquat(qi, xq, MF(body_iquat) + 4 * b);
+  quat2mat(R, qi);
+  S(gaxis)[3 * b] = R[2]; S(gaxis)[3 * b + 1] = R[5]; S(gaxis)[3 * b + 2] = R[8];
+}
+
+// gather children into parents, level by level, for an array of `w` doubles per body
+__device__ void gather_up(Ctx& c, double* arr, int w) {
+  const Aux& aux = c.P->aux;
+  for (int lvl = aux.ndepth - 2; lvl >= 1; lvl--) {
+    int a0 = AI(lvl_adr)[lvl], a1 = AI(lvl_adr)[lvl + 1];
+    for (int idx = a0 + c.lane; idx < a1; idx += WAVE) {
+      int b = AI(lvl_body)[idx];
+      int c0 = AI(child_adr)[b], c1 = AI(child_adr)[b + 1];
+      for (int ci = c0; ci < c1; ci++) {
+        int ch = AI(child)[ci];
+        for (int k = 0; k < w; k++) arr[w * b + k] += arr[w * ch + k];
+      }
+    }
+    SYNC();
+  }
+}
+
+__device__ void position_velocity(Ctx& c) {
+  const sumo_model_t& mdl = c.P->mdl;
+  const Aux& aux = c.P->aux;
+  const int lane = c.lane;
+  const int nb = mdl.nbody, nv = mdl.nv;
+  // zero M (dense) while the tree is being walked
+  for (int i = lane; i < nv * c.P->L.ld; i += WAVE) S(M)[i] = 0.0;
+  if (lane == 0) {
+    S(xpos)[0] = S(xpos)[1] = S(xpos)[2] = 0;
+    S(xquat)[0] = 1; S(xquat)[1] = S(xquat)[2] = S(xquat)[3] = 0;
+    for (int k = 0; k < 3; k++) { S(xipos)[k] = 0; S(gaxis)[k] = 0; }
+  }
+  SYNC();
+  for (int lvl = 1; lvl < aux.ndepth; lvl++) {
+    int a0 = AI(lvl_adr)[lvl], a1 = AI(lvl_adr)[lvl + 1];
+    for (int idx = a0 + lane; idx < a1; idx += WAVE) kin_body(c, AI(lvl_body)[idx]);
+    SYNC();
+  }
+  // subtree CoM of each agent's root
+  {
+    int b = lane;
+    double m = (b >= 1 && b < nb) ? MF(body_mass)[b] : 0.0;
+    int ag = (b >= 1 && b < nb) ? AI(body_agent)[b] : -1;
+    double px = 0, py = 0, pz = 0;
+    if (ag >= 0) { px = m * S(xipos)[3 * b]; py = m * S(xipos)[3 * b + 1]; pz = m * S(xipos)[3 * b + 2]; }
+    for (int a = 0; a < mdl.nagent; a++) {
+      double sx = wave_sum(ag == a ? px : 0.0), sy = wave_sum(ag == a ? py : 0.0), sz = wave_sum(ag == a ? pz : 0.0);
+      if (lane == 0) {
+        double stm = MF(body_subtreemass)[MI(agent_torso)[a]];
+        S(com)[3 * a] = sx / stm; S(com)[3 * a + 1] = sy / stm; S(com)[3 * a + 2] = sz / stm;
+      }
+    }
+  }
+  SYNC();
+  // cinert per body, cdof per joint
+  if (lane >= 1 && lane < nb) {
+    int b = lane, ag = AI(body_agent)[b];
+    const double* inert = MF(body_inertia) + 3 * b;
+    double qi[4], R[9], dif[3], T[9];
+    mulquat(qi, S(xquat) + 4 * b, MF(body_iquat) + 4 * b);
+    quat2mat(R, qi);
+    for (int k = 0; k < 3; k++) dif[k] = S(xipos)[3 * b + k] - S(com)[3 * ag + k];
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++)
+        T[3 * r + cc] = R[3 * r] * inert[0] * R[3 * cc] + R[3 * r + 1] * inert[1] * R[3 * cc + 1] + R[3 * r + 2] * inert[2] * R[3 * cc + 2];
+    double ms = MF(body_mass)[b];
+    double* res = S(cinert) + 10 * b;
+    res[0] = T[0] + ms * (dif[1] * dif[1] + dif[2] * dif[2]);
+    res[1] = T[4] + ms * (dif[0] * dif[0] + dif[2] * dif[2]);
+    res[2] = T[8] + ms * (dif[0] * dif[0] + dif[1] * dif[1]);
+    res[3] = T[1] - ms * dif[0] * dif[1];
+    res[4] = T[2] - ms * dif[0] * dif[2];
+    res[5] = T[5] - ms * dif[1] * dif[2];
+    res[6] = ms * dif[0]; res[7] = ms * dif[1]; res[8] = ms * dif[2];
+    res[9] = ms;
+  }
+  if (lane < mdl.njnt) {
+    int j = lane, b = MI(jnt_bodyid)[j], da = MI(jnt_dofadr)[j], ag = AI(body_agent)[b];
+    double off[3];
+    for (int k = 0; k < 3; k++) off[k] = S(com)[3 * ag + k] - S(xanchor)[3 * j + k];
+    if (MI(jnt_type)[j] == SUMO_JNT_FREE) {
+      double R[9];
+      quat2mat(R, S(xquat) + 4 * b);
+      for (int k = 0; k < 3; k++) {
+        double* cd = S(cdof) + 6 * (da + k);
+        cd[0] = cd[1] = cd[2] = cd[3] = cd[4] = cd[5] = 0;
+        cd[3 + k] = 1;
+      }
+      for (int k = 0; k < 3; k++) {
+        double ax[3] = {R[k], R[3 + k], R[6 + k]};
+        double* cd = S(cdof) + 6 * (da + 3 + k);
+        cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
+        cross3(cd + 3, ax, off);
+      }
+    } else {
+      double* cd = S(cdof) + 6 * da;
+      const double* ax = S(xaxis) + 3 * j;
+      cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
+      cross3(cd + 3, ax, off);
+    }
+  }
+  SYNC();
+  // body velocities along each body's dof chain; a_b = sum over the body's own dofs of cdof_dot * qvel
+  double cvel[6] = {0, 0, 0, 0, 0, 0};
+  if (lane >= 1 && lane < nb) {
+    int b = lane;
+    double a[6] = {0, 0, 0, 0, 0, 0}, cd[6];
+    const double* qvel = S(qvel);
+    int len = AI(chain_len)[b], p = 0;
+    while (p < len) {
+      int j = AI(chain)[b * MAXCHAIN + p];
+      int own = MI(dof_bodyid)[j] == b;
+      if (MI(jnt_type)[MI(dof_jntid)[j]] == SUMO_JNT_FREE) {
+        for (int k = 0; k < 3; k++)
+          for (int q = 0; q < 6; q++) cvel[q] += S(cdof)[6 * (j + k) + q] * qvel[j + k];
+        if (own)
+          for (int k = 3; k < 6; k++) {
+            cross_motion(cd, cvel, S(cdof) + 6 * (j + k));
+            for (int q = 0; q < 6; q++) a[q] += cd[q] * qvel[j + k];
+          }
+        for (int k = 3; k < 6; k++)
+          for (int q = 0; q < 6; q++) cvel[q] += S(cdof)[6 * (j + k) + q] * qvel[j + k];
+        p += 6;
+      } else {
+        if (own) {
+          cross_motion(cd, cvel, S(cdof) + 6 * j);
+          for (int q = 0; q < 6; q++) a[q] += cd[q] * qvel[j];
+        }
+        for (int q = 0; q < 6; q++) cvel[q] += S(cdof)[6 * j + q] * qvel[j];
+        p += 1;
+      }
+    }
+    for (int q = 0; q < 6; q++) S(abuf)[6 * b + q] = a[q];
+  }
+  SYNC();
+  // RNE forward: cacc along the body chain, cfrc = I*cacc + cvel x* (I*cvel)
+  if (lane < nb) {
+    int b = lane;
+    double* f = S(cfrc) + 6 * b;
+    if (b == 0) { for (int q = 0; q < 6; q++) f[q] = 0; }
+    else {
+      const double* g = MF(opt) + SUMO_OPT_GRAVITY;
+      double cacc[6] = {0, 0, 0, -g[0], -g[1], -g[2]}, t[6], t1[6];
+      int len = AI(bchain_len)[b];
+      for (int p = 0; p < len; p++) {
+        int k = AI(bchain)[b * MAXBCHAIN + p];
+        for (int q = 0; q < 6; q++) cacc[q] += S(abuf)[6 * k + q];
+      }
+      mul_inert_vec(f, S(cinert) + 10 * b, cacc);
+      mul_inert_vec(t, S(cinert) + 10 * b, cvel);
+      cross_force(t1, cvel, t);
+      for (int q = 0; q < 6; q++) f[q] += t1[q];
+    }
+  }
+  SYNC();
+  gather_up(c, S(cfrc), 6);
+  if (lane < nv) S(bias)[lane] = dot6(S(cdof) + 6 * lane, S(cfrc) + 6 * MI(dof_bodyid)[lane]);
+}
+
+__device__ void mass_matrix(Ctx& c) {
+  const sumo_model_t& mdl = c.P->mdl;
+  const int lane = c.lane, nv = mdl.nv, ld = c.P->L.ld;
+  gather_up(c, S(cinert), 10);  // cinert -> composite rigid body inertia, in place
+  if (lane < nv) {
+    int i = lane;
+    double buf[6];
+    mul_inert_vec(buf, S(cinert) + 10 * MI(dof_bodyid)[i], S(cdof) + 6 * i);
+    for (int j = i; j >= 0; j = MI(dof_parentid)[j]) {
+      double v = dot6(S(cdof) + 6 * j, buf);
+      if (j == i) S(M)[i * ld + i] = v + MF(dof_armature)[i];
+      else { S(M)[i * ld + j] = v; S(M)[j * ld + i] = v; }
+    }
+  }
+  SYNC();
+}
+
+// ---- collision ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void geom_center(const Ctx& c, int g, double* p) {
+  const sumo_model_t& mdl = c.P->mdl;
+  int b = MI(geom_bodyid)[g];
+  if (b == 0) { const double* gp = MF(geom_pos) + 3 * g; p[0] = gp[0]; p[1] = gp[1]; p[2] = gp[2]; }
+  else { const double* xp = c.sm + c.P->L.xipos + 3 * b; p[0] = xp[0]; p[1] = xp[1]; p[2] = xp[2]; }
+}
+__device__ __forceinline__ void geom_axis(const Ctx& c, int g, double* a) {
+  const sumo_model_t& mdl = c.P->mdl;
+  int b = MI(geom_bodyid)[g];
+  if (b == 0) { const double* m = c.P->aux.af + c.P->aux.o_wgmat + 9 * g; a[0] = m[2]; a[1] = m[5]; a[2] = m[8]; }
+  else { const double* ga = c.sm + c.P->L.gaxis + 3 * b; a[0] = ga[0]; a[1] = ga[1]; a[2] = ga[2]; }
+}
+
+__device__ void make_frame(double* f) {
+  double n2 = sqrt(f[3] * f[3] + f[4] * f[4] + f[5] * f[5]);
+  if (n2 < 0.5) {
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+  }
+  double dd = dot3(f, f + 3);
+  f[3] -= f[0] * dd; f[4] -= f[1] * dd; f[5] -= f[2] * dd;
+  normalize3(f + 3);
+  cross3(f + 6, f, f + 3);
+}
+
+__device__ void collision(Ctx& c) {
+  const sumo_model_t& mdl = c.P->mdl;
+  const int lane = c.lane, np = mdl.npair;
+  int* plist = c.si + c.P->L.plist;
+  // broad phase
+  int ncand = 0;
+  for (int p0 = 0; p0 < np; p0 += WAVE) {
+    int p = p0 + lane, pass = 0;
+    if (p < np) {
+      int g1 = MI(pair_geom1)[p], g2 = MI(pair_geom2)[p];
+      double margin = MF(pair_margin)[p], p1[3], p2[3];
+      geom_center(c, g1, p1);
+      geom_center(c, g2, p2);
+      double t[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+      if (MI(geom_type)[g1] == SUMO_GEOM_PLANE) {
+        double n[3];
+        geom_axis(c, g1, n);
+        pass = !(dot3(t, n) > margin + MF(geom_rbound)[g2]);
+      } else {
+        double bound = margin + MF(geom_rbound)[g1] + MF(geom_rbound)[g2];
+        pass = !(dot3(t, t) > bound * bound);
+      }
+    }
+    unsigned long long bal = __ballot(pass);
+    int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+    if (pass && pos < c.P->L.maxcand) plist[pos] = p;
+    ncand += __popcll(bal);
+  }
+  if (ncand > c.P->L.maxcand) ncand = c.P->L.maxcand;
+  SYNC();
+  // narrow phase
+  int ncon = 0, dropped = 0;
+  for (int k0 = 0; k0 < ncand; k0 += WAVE) {
+    int k = k0 + lane;
+    Con1 cs[3];
+    cs[0].ok = cs[1].ok = cs[2].ok = 0;
+    int p = 0, b1 = 0, b2 = 0;
+    double margin = 0;
+    if (k < ncand) {
+      p = plist[k];
+      int g1 = MI(pair_geom1)[p], g2 = MI(pair_geom2)[p];
+      int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
+      if (t1 == SUMO_GEOM_CYLINDER) t1 = SUMO_GEOM_CAPSULE;  // border rods as capsules
+      if (t2 == SUMO_GEOM_CYLINDER) t2 = SUMO_GEOM_CAPSULE;
+      b1 = MI(geom_bodyid)[g1]; b2 = MI(geom_bodyid)[g2];
+      margin = MF(pair_margin)[p];
+      const double* s1 = MF(geom_size) + 3 * g1;
+      const double* s2 = MF(geom_size) + 3 * g2;
+      double p1[3], p2[3], a1[3], a2[3];
+      geom_center(c, g1, p1);
+      geom_center(c, g2, p2);
+      if (t1 == SUMO_GEOM_PLANE) {
+        geom_axis(c, g1, a1);
+        if (t2 == SUMO_GEOM_SPHERE) plane_sphere(cs[0], margin, p1, a1, p2, s2[0]);
+        else if (t2 == SUMO_GEOM_CAPSULE) {
+          geom_axis(c, g2, a2);
+          double e[3];
+          for (int q = 0; q < 3; q++) e[q] = p2[q] + a2[q] * s2[1];
+          plane_sphere(cs[0], margin, p1, a1, e, s2[0]);
+          for (int q = 0; q < 3; q++) e[q] = p2[q] - a2[q] * s2[1];
+          plane_sphere(cs[1], margin, p1, a1, e, s2[0]);
+        }
+      } else if (t1 == SUMO_GEOM_SPHERE && t2 == SUMO_GEOM_SPHERE) {
+        sphere_sphere(cs[0], margin, p1, s1[0], p2, s2[0]);
+      } else if (t1 == SUMO_GEOM_SPHERE && t2 == SUMO_GEOM_CAPSULE) {
+        geom_axis(c, g2, a2);
+        double v[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+        double x = dot3(a2, v);
+        if (x > s2[1]) x = s2[1];
+        if (x < -s2[1]) x = -s2[1];
+        double e[3] = {p2[0] + a2[0] * x, p2[1] + a2[1] * x, p2[2] + a2[2] * x};
+        sphere_sphere(cs[0], margin, p1, s1[0], e, s2[0]);
+      } else if (t1 == SUMO_GEOM_CAPSULE && t2 == SUMO_GEOM_CAPSULE) {
+        geom_axis(c, g1, a1);
+        geom_axis(c, g2, a2);
+        for (int q = 0; q < 3; q++) { a1[q] *= s1[1]; a2[q] *= s2[1]; }
+        double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+        double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
+        double det = ma * mc - mb * mb, v1[3], v2[3];
+        if (fabs(det) >= MINVAL) {
+          double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+          if (x1 > 1) { x1 = 1; x2 = (v - mb) / mc; }
+          else if (x1 < -1) { x1 = -1; x2 = (v + mb) / mc; }
+          if (x2 > 1) { x2 = 1; x1 = (u - mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
+          else if (x2 < -1) { x2 = -1; x1 = (u + mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
+          for (int q = 0; q < 3; q++) { v1[q] = p1[q] + a1[q] * x1; v2[q] = p2[q] + a2[q] * x2; }
+          sphere_sphere(cs[0], margin, v1, s1[0], v2, s2[0]);
+        } else {
+          for (int si = 0; si < 2; si++) {
+            double s = si == 0 ? 1.0 : -1.0;
+            double x2 = (v - s * mb) / mc;
+            if (x2 > 1) x2 = 1; else if (x2 < -1) x2 = -1;
+            for (int q = 0; q < 3; q++) { v1[q] = p1[q] + s * a1[q]; v2[q] = p2[q] + a2[q] * x2; }
+            if (si == 0) sphere_sphere(cs[0], margin, v1, s1[0], v2, s2[0]);
+            else sphere_sphere(cs[1], margin, v1, s1[0], v2, s2[0]);
+          }
+        }
+      } else if (t2 == SUMO_GEOM_BOX) {
+        const double* bm = c.P->aux.af + c.P->aux.o_wgmat + 9 * g2;
+        if (t1 == SUMO_GEOM_SPHERE) sphere_box(cs[0], margin, p1, s1[0], p2, bm, s2);
+        else if (t1 == SUMO_GEOM_CAPSULE) {
+          geom_axis(c, g1, a1);
+          double axw[3] = {a1[0] * s1[1], a1[1] * s1[1], a1[2] * s1[1]}, e[3];
+          for (int q = 0; q < 3; q++) e[q] = p1[q] + axw[q];
+          sphere_box(cs[0], margin, e, s1[0], p2, bm, s2);
+          for (int q = 0; q < 3; q++) e[q] = p1[q] - axw[q];
+          sphere_box(cs[1], margin, e, s1[0], p2, bm, s2);
+          double t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, cc[3], a[3];
+          mulmatTvec3(cc, bm, t);
+          mulmatTvec3(a, bm, axw);
+          double glo = seg_box_dgrad(cc, a, s2, -1.0), ghi = seg_box_dgrad(cc, a, s2, 1.0);
+          if (glo < 0 && ghi > 0) {
+            double lo = -1, hi = 1;
+            for (int it = 0; it < SEGBOX_BISECT; it++) {
+              double mid = 0.5 * (lo + hi);
+              if (seg_box_dgrad(cc, a, s2, mid) > 0) hi = mid; else lo = mid;
+            }
+            double ts = 0.5 * (lo + hi);
+            for (int q = 0; q < 3; q++) e[q] = p1[q] + ts * axw[q];
+            sphere_box(cs[2], margin, e, s1[0], p2, bm, s2);
+          }
+        }
+      }
+    }
+    int act[3], n = 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++) { act[q] = cs[q].ok && (cs[q].dist < margin); n += act[q]; }
+    int total, base = wave_excl_scan(n, lane, &total);
+    int slot = ncon + base;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      if (act[q]) {
+        if (slot < c.P->L.maxcon) {
+          double* cd = S(cond) + 14 * slot;
+          double fr[9] = {cs[q].nrm[0], cs[q].nrm[1], cs[q].nrm[2], 0, 0, 0, 0, 0, 0};
+          make_frame(fr);
+          cd[0] = cs[q].dist; cd[1] = cs[q].pos[0]; cd[2] = cs[q].pos[1]; cd[3] = cs[q].pos[2];
+          for (int w = 0; w < 9; w++) cd[4 + w] = fr[w];
+          cd[13] = 0;
+          int* cb = c.si + c.P->L.con_b + 4 * slot;
+          cb[0] = b1; cb[1] = b2; cb[2] = p; cb[3] = 0;
+        }
+        slot++;
+      }
+    }
+    ncon += total;
+  }
+  if (ncon > c.P->L.maxcon) { dropped = ncon - c.P->L.maxcon; ncon = c.P->L.maxcon; }
+  c.ncon = ncon;
+  c.ndropped = dropped;
+  SYNC();
+}
+
+// ---- constraint rows -----------------------------------------------------------------------------------------
+__device__ __forceinline__ double impedance(const double* solimp, double x) {
+  double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  dmin = fmin(fmax(dmin, 0.0001), 0.9999);
+  dmax = fmin(fmax(dmax, 0.0001), 0.9999);
+  if (width < MINVAL) width = MINVAL;
+  mid = fmin(fmax(mid, 0.0001), 0.9999);
+  if (power < 1) power = 1;
+  double xx = fabs(x) / width, y;
+  if (xx >= 1) return dmax;
+  if (xx <= 0) return dmin;
+  if (power == 1) y = xx;
+  else if (xx <= mid) y = pow(xx, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - xx, power) / pow(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+// returns R; writes B and K*imp*(pos-margin)
+__device__ __forceinline__ double row_params(double timestep, const double* solref, const double* solimp, double pos, double margin,
+                                             double diag, double* B, double* kterm) {
+  double tc = solref[0], dr = solref[1], dmax = fmin(fmax(solimp[1], 0.0001), 0.9999);
+  if (tc < 2 * timestep) tc = 2 * timestep;
+  double imp = impedance(solimp, pos - margin);
+  double kk = dmax * dmax * tc * tc * dr * dr, bb = dmax * tc;
+  double K = 1.0 / (kk < MINVAL ? MINVAL : kk);
+  *B = 2.0 / (bb < MINVAL ? MINVAL : bb);
+  *kterm = K * imp * (pos - margin);
+  double R = (1 - imp) * diag / imp;
+  return R < MINVAL ? MINVAL : R;
+}
+
+__device__ void make_constraint(Ctx& c) {
+  const sumo_model_t& mdl = c.P->mdl;
+  const Aux& aux = c.P->aux;
+  const int lane = c.lane, nv = mdl.nv, ncon = c.ncon;
+  const double timestep = MF(opt)[SUMO_OPT_TIMESTEP];
+  const double def_solref[2] = {0.02, 1.0};
+  const double def_solimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+  int* lim_dof = c.si + c.P->L.lim_dof;
+  double* lim_sign = (double*)(c.si + c.P->L.lim_sign);
+  // joint limits (lower side first, then upper, joints in order)
+  int nact = 0, act_lo = 0, act_hi = 0;
+  double dlo = 0, dhi = 0, jm = 0;
+  int j = lane;
+  if (j < mdl.njnt && MI(jnt_type)[j] == SUMO_JNT_HINGE && MI(jnt_limited)[j]) {
+    double value = S(qpos)[MI(jnt_qposadr)[j]];
+    jm = MF(jnt_margin)[j];
+    dlo = value - MF(jnt_range)[2 * j];
+    dhi = MF(jnt_range)[2 * j + 1] - value;
+    act_lo = dlo < jm; act_hi = dhi < jm;
+    nact = act_lo + act_hi;
+  }
+  int nlim, base = wave_excl_scan(nact, lane, &nlim);
+  if (nact) {
+    int dof = MI(jnt_dofadr)[j], r = base;
+    double diag = MF(dof_invweight0)[dof];
+    if (act_lo) {
+      double B, kt, R = row_params(timestep, def_solref, def_solimp, dlo, jm, diag, &B, &kt);
+      lim_dof[r] = dof; lim_sign[r] = 1.0; S(D)[r] = 1.0 / R; S(Jv)[r] = B; S(jar)[r] = kt; r++;
+    }
+    if (act_hi) {
+      double B, kt, R = row_params(timestep, def_solref, def_solimp, dhi, jm, diag, &B, &kt);
+      lim_dof[r] = dof; lim_sign[r] = -1.0; S(D)[r] = 1.0 / R; S(Jv)[r] = B; S(jar)[r] = kt; r++;
+    }
+  }
+  c.nlim = nlim;
+  c.nefc = nlim + 4 * ncon;
+  // contact row parameters (same for the 4 pyramid edges of a contact)
+  for (int ci = lane; ci < ncon; ci += WAVE) {
+    const double* cd = S(cond) + 14 * ci;
+    const int* cb = c.si + c.P->L.con_b + 4 * ci;
+    int p = cb[2];
+    double mu = MF(pair_friction)[3 * p];
+    double tran = MF(body_invweight0)[2 * cb[0]] + MF(body_invweight0)[2 * cb[1]];
+    double diag = tran + mu * mu * tran, B, kt;
+    double margin = MF(pair_margin)[p] - MF(pair_gap)[p];
+    double R = row_params(timestep, MF(pair_solref) + 2 * p, MF(pair_solimp) + 5 * p, cd[0], margin, diag, &B, &kt);
+    double Rpy = 2 * mu * mu * R;
+    if (Rpy < MINVAL) Rpy = MINVAL;
+    S(cpar)[4 * ci] = mu;
+    for (int k = 0; k < 4; k++) { int r = nlim + 4 * ci + k; S(D)[r] = 1.0 / Rpy; S(Jv)[r] = B; S(jar)[r] = kt; }
+  }
+  // slot map init
+  unsigned char* slotof = c.sb + c.P->L.b_slotof;
+  for (int i = lane; i < ncon * nv; i += WAVE) slotof[i] = 0xFF;
+  SYNC();
+  // compact contact Jacobians: 3 base rows (normal, t1, t2) x 16 slots (chain of body1 | chain of body2)
+  for (int idx = lane; idx < ncon * 16; idx += WAVE) {
+    int ci = idx >> 4, s = idx & 15, side = s >> 3, pos = s & 7;
+    const int* cb = c.si + c.P->L.con_b + 4 * ci;
+    int body = side ? cb[1] : cb[0], other = side ? cb[0] : cb[1];
+    int dof = -1;
+    double j0 = 0, j1 = 0, j2 = 0;
+    if (body != 0 && pos < AI(chain_len)[body]) {
+      dof = AI(chain)[body * MAXCHAIN + pos];
+      if (other != 0 && aux.pic[other * nv + dof] >= 0) dof = -1;  // shared ancestor dof: contributions cancel
+    }
+    if (dof >= 0) {
+      const double* cd = S(cond) + 14 * ci;
+      const double* cdf = S(cdof) + 6 * dof;
+      int ag = AI(body_agent)[body];
+      double off[3] = {cd[1] - S(com)[3 * ag], cd[2] - S(com)[3 * ag + 1], cd[3] - S(com)[3 * ag + 2]}, t[3];
+      cross3(t, cdf, off);
+      t[0] += cdf[3]; t[1] += cdf[4]; t[2] += cdf[5];
+      double sg = side ? 1.0 : -1.0;
+      j0 = sg * dot3(cd + 4, t); j1 = sg * dot3(cd + 7, t); j2 = sg * dot3(cd + 10, t);
+      slotof[ci * nv + dof] = (unsigned char)s;
+    }
+    c.si[c.P->L.dofidx + idx] = dof;
+    double* Jb = S(Jb) + 48 * ci;
+    Jb[s] = j0; Jb[16 + s] = j1; Jb[32 + s] = j2;
+  }
+  SYNC();
+}
+
+// cp[3*c + a] = sum_s Jb[c][a][s] * x[dof(c,s)]
+__device__ void contact_Jx(Ctx& c, const double* x) {
+  for (int idx = c.lane; idx < 3 * c.ncon; idx += WAVE) {
+    int ci = idx / 3, a = idx - 3 * ci;
+    const double* Jb = S(Jb) + 48 * ci + 16 * a;
+    const int* di = c.si + c.P->L.dofidx + 16 * ci;
+    double acc = 0;
+    for (int s = 0; s < 16; s++) { int d = di[s]; if (d >= 0) acc += Jb[s] * x[d]; }
+    S(cp)[idx] = acc;
+  }
+  SYNC();
+}
+// value of row r of J*x given cp (after contact_Jx)
+__device__ __forceinline__ double row_Jx(const Ctx& c, int r, const double* x) {
+  if (r < c.nlim) return ((const double*)(c.si + c.P->L.lim_sign))[r] * x[(c.si + c.P->L.lim_dof)[r]];
+  int q = r - c.nlim, ci = q >> 2, k = q & 3;
+  double mu = c.sm[c.P->L.cpar + 4 * ci];
+  const double* cp = c.sm + c.P->L.cp + 3 * ci;
+  return cp[0] + ((k & 1) ? -mu : mu) * cp[1 + (k >> 1)];
+}
+
+// y_i = sum_k M[i][k] x[k]   (x in LDS)
+__device__ __forceinline__ double dense_Mx(const Ctx& c, const double* x) {
+  double acc = 0;
+  if (c.lane < c.P->mdl.nv) {
+    const double* row = c.sm + c.P->L.M + c.lane * c.P->L.ld;
+    for (int k = 0; k < c.P->mdl.nv; k++) acc += row[k] * x[k];
+  }
+  return acc;
+}
+
+// in-place Cholesky of the lower triangle of A (LDS, leading dim ld); returns 0 ok (wave-uniform)
+__device__ int cholesky_lds(Ctx& c, double* A, int n) {
+  const int lane = c.lane, ld = c.P->L.ld;
+  int fail = 0;
+  for (int j = 0; j < n; j++) {
+    double s = 0;
+    if (lane >= j && lane < n) {
+      const double* ri = A + lane * ld;
+      const double* rj = A + j * ld;
+      s = ri[j];
+      for (int k = 0; k < j; k++) s -= ri[k] * rj[k];
+    }
+    double sj = __shfl(s, j, WAVE);
+    if (sj < MINVAL) { fail = 1; break; }
+    double d = sqrt(sj);
+    if (lane == j) A[j * ld + j] = d;
+    else if (lane > j && lane < n) A[lane * ld + j] = s / d;
+    SYNC();
+  }
+  return fail;
+}
+// solve L L^T x = b; lane i holds b_i on entry and x_i on return
+__device__ double chol_solve_lds(Ctx& c, const double* Lm, int n, double b) {
+  const int lane = c.lane, ld = c.P->L.ld;
+  double y = b;
+  double dinv = (lane < n) ? 1.0 / Lm[lane * ld + lane] : 0.0;
+  for (int k = 0; k < n; k++) {
+    double yk = __shfl(y, k, WAVE) * __shfl(dinv, k, WAVE);
+    if (lane == k) y = yk;
+    else if (lane > k && lane < n) y -= Lm[lane * ld + k] * yk;
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    double xk = __shfl(y, k, WAVE) * __shfl(dinv, k, WAVE);
+    if (lane == k) y = xk;
+    else if (lane < k) y -= Lm[k * ld + lane] * xk;
+  }
+  return y;
+}
+
+// cost(x) = 1/2 (Ma - qfrc_smooth).(x - qacc_smooth) + sum_active 1/2 D jar^2
+__device__ double solver_cost(Ctx& c, double Ma_i, double x_i) {
+  const int lane = c.lane, nv = c.P->mdl.nv;
+  double v = 0;
+  if (lane < nv) v = 0.5 * (Ma_i - S(qsm)[lane]) * (x_i - S(asmo)[lane]);
+  for (int r = lane; r < c.nefc; r += WAVE) { double j = S(jar)[r]; if (j < 0) v += 0.5 * S(D)[r] * j * j; }
+  return wave_sum(v);
+}
+
+__device__ void newton_solve(Ctx& c) {
+  const sumo_model_t& mdl = c.P->mdl;
+  const Aux& aux = c.P->aux;
+  const int lane = c.lane, nv = mdl.nv, ld = c.P->L.ld, nefc = c.nefc, ncon = c.ncon, nlim = c.nlim;
+  const double tol = MF(opt)[SUMO_OPT_TOLERANCE];
+  const int maxiter = (int)MF(opt)[SUMO_OPT_ITERATIONS];
+  const double scale = 1.0 / (MF(opt)[SUMO_OPT_MEANINERTIA] * (nv > 1 ? nv : 1));
+  double* x = S(x);
+  if (nefc == 0) {
+    if (lane < nv) x[lane] = S(asmo)[lane];
+    SYNC();
+    return;
+  }
+  const unsigned char* slotof = c.sb + c.P->L.b_slotof;
+  // ---- warm start: better of qacc_warmstart and qacc_smooth
+  if (lane < nv) x[lane] = S(warm)[lane];
+  SYNC();
+  double Ma = dense_Mx(c, x);
+  contact_Jx(c, x);
+  for (int r = lane; r < nefc; r += WAVE) S(jar)[r] = row_Jx(c, r, x) - S(aref)[r];
+  SYNC();
+  double xi = lane < nv ? x[lane] : 0.0;
+  double cost_ws = solver_cost(c, Ma, xi);
+  contact_Jx(c, S(asmo));
+  double csm = 0;
+  for (int r = lane; r < nefc; r += WAVE) {
+    double jv = row_Jx(c, r, S(asmo)) - S(aref)[r];
+    S(Jv)[r] = jv;
+    if (jv < 0) csm += 0.5 * S(D)[r] * jv * jv;
+  }
+  double cost_sm = wave_sum(csm);
+  SYNC();
+  double cost = cost_ws;
+  if (cost_ws > cost_sm) {
+    if (lane < nv) { xi = S(asmo)[lane]; x[lane] = xi; }
+    for (int r = lane; r < nefc; r += WAVE) S(jar)[r] = S(Jv)[r];
+    SYNC();
+    Ma = dense_Mx(c, x);
+    cost = solver_cost(c, Ma, xi);
+  }
+  int iters = 0;
+  for (int iter = 0; iter < maxiter; iter++) {
+    iters++;
+    // ---- per-contact force / weight summaries of the active set
+    for (int ci = lane; ci < ncon; ci += WAVE) {
+      double mu = S(cpar)[4 * ci], f[4], dact[4];
+      for (int k = 0; k < 4; k++) {
+        int r = nlim + 4 * ci + k;
+        double j = S(jar)[r], Dr = S(D)[r];
+        dact[k] = j < 0 ? Dr : 0.0;
+        f[k] = j < 0 ? -Dr * j : 0.0;
+      }
+      double* cp = S(cp) + 3 * ci;
+      cp[0] = ((f[0] + f[1]) + f[2]) + f[3];
+      cp[1] = mu * (f[0] - f[1]);
+      cp[2] = mu * (f[2] - f[3]);
+      double* W = S(cW) + 6 * ci;
+      W[0] = ((dact[0] + dact[1]) + dact[2]) + dact[3];
+      W[1] = mu * (dact[0] - dact[1]);
+      W[2] = mu * (dact[2] - dact[3]);
+      W[3] = mu * mu * (dact[0] + dact[1]);
+      W[4] = mu * mu * (dact[2] + dact[3]);
+    }
+    SYNC();
+    // ---- gradient (dof-major gather of J^T f) and limit-row diagonal
+    double g = 0;
+    if (lane < nv) {
+      double qc = 0, dl = 0;
+      const int* lim_dof = c.si + c.P->L.lim_dof;
+      const double* lim_sign = (const double*)(c.si + c.P->L.lim_sign);
+      for (int r = 0; r < nlim; r++)
+        if (lim_dof[r] == lane) {
+          double j = S(jar)[r];
+          if (j < 0) { qc += lim_sign[r] * (-S(D)[r] * j); dl += S(D)[r]; }
+        }
+      for (int ci = 0; ci < ncon; ci++) {
+        int s = slotof[ci * nv + lane];
+        if (s != 0xFF) {
+          const double* Jb = S(Jb) + 48 * ci;
+          const double* cp = S(cp) + 3 * ci;
+          qc += Jb[s] * cp[0] + Jb[16 + s] * cp[1] + Jb[32 + s] * cp[2];
+        }
+      }
+      g = Ma - S(qsm)[lane] - qc;
+      S(grad)[lane] = g;
+      S(dlim)[lane] = dl;
+    }
+    double gn = wave_sum(g * g);
+    if (scale * sqrt(gn) < tol) break;
+    SYNC();
+    // ---- Hessian H = M + J^T diag(D_active) J, lower triangle, entry-major gather
+    for (int t = lane; t < aux.ntri; t += WAVE) {
+      int i = AI(tri_i)[t], jj = AI(tri_j)[t];
+      double h = S(M)[i * ld + jj];
+      if (i == jj) h += S(dlim)[i];
+      for (int ci = 0; ci < ncon; ci++) {
+        int si = slotof[ci * nv + i], sj = slotof[ci * nv + jj];
+        if (si != 0xFF && sj != 0xFF) {
+          const double* Jb = S(Jb) + 48 * ci;
+          const double* W = S(cW) + 6 * ci;
+          double a0 = Jb[si], a1 = Jb[16 + si], a2 = Jb[32 + si], b0 = Jb[sj], b1 = Jb[16 + sj], b2 = Jb[32 + sj];
+          h += a0 * (W[0] * b0 + W[1] * b1 + W[2] * b2) + a1 * (W[1] * b0 + W[3] * b1) + a2 * (W[2] * b0 + W[4] * b2);
+        }
+      }
+      S(H)[i * ld + jj] = h;
+    }
+    SYNC();
+    if (cholesky_lds(c, S(H), nv)) break;
+    double sr = -chol_solve_lds(c, S(H), nv, lane < nv ? S(grad)[lane] : 0.0);
+    if (lane < nv) S(search)[lane] = sr;
+    SYNC();
+    // ---- exact line search
+    double Mv = dense_Mx(c, S(search));
+    contact_Jx(c, S(search));
+    for (int r = lane; r < nefc; r += WAVE) S(Jv)[r] = row_Jx(c, r, S(search));
+    double g1 = wave_sum(lane < nv ? sr * (Ma - S(qsm)[lane]) : 0.0);
+    double g2 = wave_sum(lane < nv ? sr * Mv : 0.0);
+    SYNC();
+    double alpha = 0, lo = 0, hi = -1, d0 = 0;
+    for (int ls = 0; ls < 50; ls++) {
+      double f1 = 0, f2 = 0;
+      for (int r = lane; r < nefc; r += WAVE) {
+        double jv = S(Jv)[r], j = S(jar)[r] + alpha * jv;
+        if (j < 0) { double Dr = S(D)[r]; f1 += Dr * j * jv; f2 += Dr * jv * jv; }
+      }
+      f1 = wave_sum(f1) + (g1 + alpha * g2);
+      f2 = wave_sum(f2) + g2;
+      if (ls == 0) d0 = fabs(f1);
+      if (fabs(f1) <= 1e-10 * d0) break;
+      if (f1 < 0) lo = alpha; else hi = alpha;
+      double an = alpha - f1 / f2;
+      if (an <= lo || (hi >= 0 && an >= hi)) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * (alpha > 0 ? alpha : 1.0);
+      alpha = an;
+    }
+    if (alpha == 0) break;
+    if (lane < nv) { xi += alpha * sr; x[lane] = xi; Ma += alpha * Mv; }
+    for (int r = lane; r < nefc; r += WAVE) S(jar)[r] += alpha * S(Jv)[r];
+    SYNC();
+    double oldcost = cost;
+    cost = solver_cost(c, Ma, xi);
+    if (scale * (oldcost - cost) < tol) break;
+  }
+  c.st_newton += iters;
+  if (iters > c.st_maxnewton) c.st_maxnewton = iters;
+  SYNC();
+}
+
+// ---- mj_forward ----------------------------------------------------------------------------------------------
+__device__ void forward(Ctx& c) {
+  const sumo_model_t& mdl = c.P->mdl;
+  const int lane = c.lane, nv = mdl.nv;
+  c.st_forward++;
+  position_velocity(c);
+  collision(c);
+  make_constraint(c);
+  // efc_vel and aref (B and K*imp*(pos-margin) were parked in Jv / jar)
+  contact_Jx(c, S(qvel));
+  for (int r = lane; r < c.nefc; r += WAVE) S(aref)[r] = -S(Jv)[r] * row_Jx(c, r, S(qvel)) - S(jar)[r];
+  SYNC();
+  mass_matrix(c);  // last user of the kinematic scratch; H may overwrite it from here on
+  // smooth forces: passive (damping) - bias + actuation
+  if (lane < nv) S(qsm)[lane] = -MF(dof_damping)[lane] * S(qvel)[lane] - S(bias)[lane];
+  SYNC();
+  if (lane < mdl.nu) {
+    double u = S(ctrl)[lane], lo = MF(actuator_ctrlrange)[2 * lane], hi = MF(actuator_ctrlrange)[2 * lane + 1];
+    if (u < lo) u = lo;
+    if (u > hi) u = hi;
+    S(qsm)[MI(actuator_dofid)[lane]] += MF(actuator_gear)[lane] * u;  // one motor per dof in these scenes
+  }
+  SYNC();
+  // qacc_smooth = M^-1 qfrc_smooth
+  for (int i = lane; i < nv * c.P->L.ld; i += WAVE) S(H)[i] = S(M)[i];
+  SYNC();
+  int fail = cholesky_lds(c, S(H), nv);
+  double as = fail ? 0.0 : chol_solve_lds(c, S(H), nv, lane < nv ? S(qsm)[lane] : 0.0);
+  if (lane < nv) S(asmo)[lane] = as;
+  SYNC();
+  newton_solve(c);
+  c.st_ncon += c.ncon;
+  c.st_nefc += c.nefc;
+  if (c.ncon > c.st_maxcon) c.st_maxcon = c.ncon;
+  if (c.nefc > c.st_maxefc) c.st_maxefc = c.nefc;
+  c.st_dropped += c.ndropped;
+}
+
+// qpos '+'= h * vel  (vel in LDS), one lane per joint
+__device__ void integrate_pos(Ctx& c, double* qpos, const double* vel, double h) {
+  const sumo_model_t& mdl = c.P->mdl;
+  int j = c.lane;
+  if (j < mdl.njnt) {
+    int qa = MI(jnt_qposadr)[j], da = MI(jnt_dofadr)[j];
+    if (MI(jnt_type)[j] == SUMO_JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos[qa + k] += h * vel[da + k];
+      double ax[3] = {vel[da + 3], vel[da + 4], vel[da + 5]}, qr[4], q[4] = {qpos[qa + 3], qpos[qa + 4], qpos[qa + 5], qpos[qa + 6]};
+      double ang = h * normalize3(ax);
+      axisangle2quat(qr, ax, ang);
+      normalize4(q);
+      mulquat(q, q, qr);
+      qpos[qa + 3] = q[0]; qpos[qa + 4] = q[1]; qpos[qa + 5] = q[2]; qpos[qa + 6] = q[3];
+    } else {
+      qpos[qa] += h * vel[da];
+    }
+  }
+}
+
+__device__ void mj_step(Ctx& c) {
+  const sumo_model_t& mdl = c.P->mdl;
+  const int lane = c.lane, nq = mdl.nq, nv = mdl.nv;
+  const double h = MF(opt)[SUMO_OPT_TIMESTEP];
+  forward(c);
+  if (lane < nq) S(x0)[lane] = S(qpos)[lane];
+  if (lane < nv) {
+    S(x0)[nq + lane] = S(qvel)[lane];
+    S(accv)[lane] = 0.0 + (1.0 / 6.0) * S(qvel)[lane];
+    S(acca)[lane] = 0.0 + (1.0 / 6.0) * S(x)[lane];
+  }
+  SYNC();
+  for (int i = 1; i < 4; i++) {
+    // RK4 tableau: A = diag(1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
+    const double Ai = i == 3 ? 1.0 : 0.5, Bi = i == 3 ? 1.0 / 6.0 : 1.0 / 3.0;
+    double dv = 0;
+    if (lane < nv) { S(tmpv)[lane] = Ai * S(qvel)[lane]; dv = Ai * S(x)[lane]; }
+    if (lane < nq) S(qpos)[lane] = S(x0)[lane];
+    SYNC();
+    integrate_pos(c, S(qpos), S(tmpv), h);
+    if (lane < nv) S(qvel)[lane] = S(x0)[nq + lane] + h * dv;
+    SYNC();
+    forward(c);
+    if (lane < nv) { S(accv)[lane] += Bi * S(qvel)[lane]; S(acca)[lane] += Bi * S(x)[lane]; }
+    SYNC();
+  }
+  if (lane < nq) S(qpos)[lane] = S(x0)[lane];
+  if (lane < nv) { S(qvel)[lane] = S(x0)[nq + lane] + h * S(acca)[lane]; S(warm)[lane] = S(x)[lane]; }
+  SYNC();
+  integrate_pos(c, S(qpos), S(accv), h);
+  SYNC();
+}
+
+// ---- RNG / reset / observation -----------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32(uint32_t* out, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double rng_uniform(uint64_t seed, uint32_t reset_count, uint32_t k) {
+  uint32_t o[4];
+  philox4x32(o, reset_count, k >> 1, 0u, 0x53554D4Fu, (uint32_t)seed, (uint32_t)(seed >> 32));
+  uint32_t a = ((k & 1) ? o[2] : o[0]) >> 5, b = ((k & 1) ? o[3] : o[1]) >> 6;
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+// sumo.py:232-253 with a counter RNG; state ends up in LDS (qpos, qvel, warm)
+__device__ void reset_state(Ctx& c, uint64_t seed, uint32_t rc) {
+  const sumo_model_t& mdl = c.P->mdl;
+  const int lane = c.lane, nq = mdl.nq, nv = mdl.nv;
+  if (lane < nq) S(qpos)[lane] = MF(qpos0)[lane];
+  SYNC();
+  if (lane < mdl.nagent) {
+    double phi = 2.0 * PI_D * rng_uniform(seed, rc, 0);
+    double ang = phi + lane * (2.0 * PI_D / 2.0);
+    int qa = MI(agent_qposadr)[lane];
+    S(qpos)[qa] = 1.15 * cos(ang);
+    S(qpos)[qa + 1] = 1.15 * sin(ang);
+    S(qpos)[qa + 2] = 1.25;
+  }
+  SYNC();
+  if (lane < nq) S(qpos)[lane] += -0.1 + 0.2 * rng_uniform(seed, rc, 1 + lane);
+  if (lane < nv) {
+    double u1 = rng_uniform(seed, rc, RNG_NORMAL_BASE + 2 * (lane >> 1));
+    double u2 = rng_uniform(seed, rc, RNG_NORMAL_BASE + 2 * (lane >> 1) + 1);
+    double rr = sqrt(-2.0 * log(1.0 - u1));
+    double z = (lane & 1) ? rr * sin(2.0 * PI_D * u2) : rr * cos(2.0 * PI_D * u2);
+    S(qvel)[lane] = 0.1 * z;
+    S(warm)[lane] = 0.0;
+  }
+  SYNC();
+  if (lane < mdl.njnt && MI(jnt_type)[lane] == SUMO_JNT_FREE) {
+    double* q = S(qpos) + MI(jnt_qposadr)[lane] + 3;
+    double qq[4] = {q[0], q[1], q[2], q[3]};
+    normalize4(qq);
+    q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+  }
+  SYNC();
+}
+
+// agents.py:190-214 (cfrc_ext == 0) + time feature (sumo_env.py:68-70)
+__device__ void write_obs(Ctx& c, float* obs, int obs_stride, int num_steps) {
+  const sumo_model_t& mdl = c.P->mdl;
+  for (int idx = c.lane; idx < 2 * obs_stride; idx += WAVE) {
+    int a = idx >= obs_stride, k = idx - a * obs_stride, o = 1 - a;
+    int nqa = MI(agent_nq)[a], nva = MI(agent_nv)[a], nba = MI(agent_nbody)[a];
+    int dim = nqa + nva + 6 * nba + 14;
+    float v = 0.0f;
+    if (k < nqa) v = (float)S(qpos)[MI(agent_qposadr)[a] + k];
+    else if (k < nqa + nva) v = (float)S(qvel)[MI(agent_dofadr)[a] + (k - nqa)];
+    else if (k < nqa + nva + 6 * nba) v = 0.0f;
+    else if (k < nqa + nva + 6 * nba + 7) v = (float)S(qpos)[MI(agent_qposadr)[o] + (k - nqa - nva - 6 * nba)];
+    else if (k < dim - 1) v = 0.0f;
+    else if (k == dim - 1) v = (float)(-1.0 + 2.0 * num_steps / 500.0);
+    obs[idx] = v;
+  }
+}
+
+__device__ float sumsq_f32(const float* a, int n) {  // numpy float32 pairwise sum of squares (n < 128)
+  if (n < 8) { float r = 0.0f; for (int i = 0; i < n; i++) r += a[i] * a[i]; return r; }
+  float r[8];
+  for (int j = 0; j < 8; j++) r[j] = a[j] * a[j];
+  int i;
+  for (i = 8; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; j++) r[j] += a[i + j] * a[i + j];
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; i++) res += a[i] * a[i];
+  return res;
+}
+
+__device__ void ctx_init(Ctx& c, const Params* P, double* smem) {
+  c.P = P;
+  c.sm = smem;
+  c.si = (int*)(smem + P->L.i_base);
+  c.sb = (unsigned char*)(smem + P->L.i_base);
+  c.lane = threadIdx.x;
+  c.ncon = c.nlim = c.nefc = c.ndropped = 0;
+  c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = 0;
+}
+__device__ void load_state(Ctx& c, const StepArgs& a, int e) {
+  const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
+  const double* st = a.state + (size_t)e * a.state_stride;
+  for (int i = lane; i < nq + 2 * nv; i += WAVE) {
+    double v = st[i];
+    if (i < nq) S(qpos)[i] = v; else if (i < nq + nv) S(qvel)[i - nq] = v; else S(warm)[i - nq - nv] = v;
+  }
+}
+__device__ void store_state(Ctx& c, const StepArgs& a, int e) {
+  const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
+  double* st = a.state + (size_t)e * a.state_stride;
+  for (int i = lane; i < nq + 2 * nv; i += WAVE)
+    st[i] = i < nq ? S(qpos)[i] : (i < nq + nv ? S(qvel)[i - nq] : S(warm)[i - nq - nv]);
+}
+__device__ void flush_stats(Ctx& c, unsigned long long* stats) {
+  if (c.lane == 0 && stats) {
+    atomicAdd(stats + 0, (unsigned long long)c.st_forward);
+    atomicAdd(stats + 1, (unsigned long long)c.st_newton);
+    atomicAdd(stats + 2, (unsigned long long)c.st_ncon);
+    atomicAdd(stats + 3, (unsigned long long)c.st_nefc);
+    atomicMax(stats + 4, (unsigned long long)c.st_maxcon);
+    atomicMax(stats + 5, (unsigned long long)c.st_maxefc);
+    atomicMax(stats + 6, (unsigned long long)c.st_maxnewton);
+    atomicAdd(stats + 7, (unsigned long long)c.st_dropped);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------
+extern __shared__ double smem_dyn[];
+
+__global__ void __launch_bounds__(WAVE) sumo_step_kernel(const Params* P, StepArgs a) {
+  Ctx c;
+  ctx_init(c, P, smem_dyn);
+  const sumo_model_t& mdl = P->mdl;
+  const int e = blockIdx.x, lane = c.lane;
+  if (e >= a.N) return;
+  load_state(c, a, e);
+  const float* act = a.actions + (size_t)e * 2 * a.act_stride;
+  if (lane < mdl.nu) {
+    int ag = lane >= MI(agent_uadr)[1] ? 1 : 0;
+    S(ctrl)[lane] = (double)act[ag * a.act_stride + (lane - MI(agent_uadr)[ag])];
+  }
+  int* cnt = a.counters + 4 * e;
+  int num_steps = cnt[0], reset_count = cnt[1];
+  double* st = a.state + (size_t)e * a.state_stride;
+  double ep_ret = st[mdl.nq + 2 * mdl.nv], ep_dense = st[mdl.nq + 2 * mdl.nv + 1];
+  SYNC();
+  double before[2][2];
+  for (int g = 0; g < 2; g++) { int qa = MI(agent_qposadr)[g]; before[g][0] = S(qpos)[qa]; before[g][1] = S(qpos)[qa + 1]; }
+  SYNC();
+  for (int f = 0; f < mdl.frame_skip; f++) mj_step(c);
+  // ---- game rules (sumo.py:120-202), evaluated redundantly by every lane (wave-uniform result)
+  double after[2][2], z[2];
+  for (int g = 0; g < 2; g++) {
+    int qa = MI(agent_qposadr)[g];
+    after[g][0] = S(qpos)[qa]; after[g][1] = S(qpos)[qa + 1]; z[g] = S(qpos)[qa + 2];
+  }
+  num_steps++;
+  const double lim = mdl.tatami_size + 0.1;
+  int lost[2];
+  for (int g = 0; g < 2; g++) {
+    double mx = fabs(after[g][0]) > fabs(after[g][1]) ? fabs(after[g][0]) : fabs(after[g][1]);
+    lost[g] = (z[g] < 0.29) || (mx >= lim);
+  }
+  const double dt = MF(opt)[SUMO_OPT_TIMESTEP] * mdl.frame_skip;
+  int dn = 0;
+  double inf[2][SUMO_INFO_STRIDE];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    int o = 1 - g, flags = 0;
+    double ctrl_r = -0.1 * (double)sumsq_f32(act + g * a.act_stride, MI(agent_nu)[g]);
+    double lose = lost[g] ? -2000.0 : 0.0, win = lost[o] ? 2000.0 : 0.0;
+    if (lost[g] || lost[o]) dn = 1;
+    if (lost[o]) flags |= 1;
+    double main_r = win + lose;
+    if (num_steps > mdl.timestep_limit) { main_r += -1000.0; dn = 1; }
+    double mv[2] = {(after[g][0] - before[g][0]) / dt, (after[g][1] - before[g][1]) / dt};
+    double dir[2] = {after[o][0] - before[g][0], after[o][1] - before[g][1]};
+    double nrm = sqrt(dir[0] * dir[0] + dir[1] * dir[1]);
+    dir[0] /= nrm; dir[1] /= nrm;
+    double proj = mv[0] * dir[0] + mv[1] * dir[1];
+    double move = (proj > 0 ? proj : 0.0) * 0.1;
+    double push = -10.0 * exp(-sqrt(after[o][0] * after[o][0] + after[o][1] * after[o][1]));
+    double shaping = ctrl_r + push + move;
+    inf[g][0] = ctrl_r; inf[g][1] = lose; inf[g][2] = win; inf[g][3] = main_r; inf[g][4] = move; inf[g][5] = push;
+    inf[g][6] = shaping; inf[g][7] = (double)flags;
+  }
+  ep_ret += inf[0][3] + inf[0][6];
+  ep_dense += inf[0][6];
+  if (dn && inf[0][3] == -1000.0) { inf[0][7] += 2.0; inf[1][7] += 2.0; }
+  if (lane == 0) {
+    double* io = a.info + (size_t)e * 2 * SUMO_INFO_STRIDE;
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+      for (int k = 0; k < SUMO_INFO_STRIDE; k++) io[g * SUMO_INFO_STRIDE + k] = inf[g][k];
+  }
+  if (lane < 2) a.done[2 * e + lane] = (uint8_t)dn;
+  if (lane == 0) { a.ep_r[e] = dn ? ep_ret : 0.0; a.ep_dr[e] = dn ? ep_dense : 0.0; a.ep_l[e] = dn ? num_steps : 0; }
+  if (dn) {  // subproc_vec_env.py:13-16: auto-reset, reset observation replaces the terminal one
+    reset_state(c, a.seeds[e], (uint32_t)reset_count);
+    reset_count++;
+    num_steps = 0; ep_ret = 0; ep_dense = 0;
+  }
+  write_obs(c, a.obs + (size_t)e * 2 * a.obs_stride, a.obs_stride, num_steps);
+  store_state(c, a, e);
+  if (lane == 0) { cnt[0] = num_steps; cnt[1] = reset_count; st[mdl.nq + 2 * mdl.nv] = ep_ret; st[mdl.nq + 2 * mdl.nv + 1] = ep_dense; }
+  flush_stats(c, a.stats);
+}
+
+__global__ void __launch_bounds__(WAVE) sumo_reset_kernel(const Params* P, StepArgs a) {
+  Ctx c;
+  ctx_init(c, P, smem_dyn);
+  const sumo_model_t& mdl = P->mdl;
+  const int e = blockIdx.x, lane = c.lane;
+  if (e >= a.N) return;
+  if (a.mask && !a.mask[e]) return;
+  int* cnt = a.counters + 4 * e;
+  int reset_count = cnt[1];
+  reset_state(c, a.seeds[e], (uint32_t)reset_count);
+  if (a.obs) write_obs(c, a.obs + (size_t)e * 2 * a.obs_stride, a.obs_stride, 0);
+  store_state(c, a, e);
+  if (lane == 0) {
+    double* st = a.state + (size_t)e * a.state_stride;
+    cnt[0] = 0; cnt[1] = reset_count + 1;
+    st[mdl.nq + 2 * mdl.nv] = 0; st[mdl.nq + 2 * mdl.nv + 1] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(WAVE) sumo_forward_kernel(const Params* P, StepArgs a) {
+  Ctx c;
+  ctx_init(c, P, smem_dyn);
+  const sumo_model_t& mdl = P->mdl;
+  const int e = blockIdx.x, lane = c.lane;
+  if (e >= a.N) return;
+  load_state(c, a, e);
+  if (lane < mdl.nu) S(ctrl)[lane] = a.dbg_ctrl[(size_t)e * mdl.nu + lane];
+  SYNC();
+  forward(c);
+  if (lane < mdl.nv) a.dbg_qacc[(size_t)e * mdl.nv + lane] = S(x)[lane];
+  if (lane == 0) {
+    int* o = a.dbg_counts + 4 * e;
+    o[0] = c.ncon; o[1] = c.nefc; o[2] = c.st_newton; o[3] = c.ndropped;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512];
+extern "C" const char* sumo_last_error(void) { return g_err; }
+#define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return code; } while (0)
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) FAIL(-100, "%s failed: %s", #expr, hipGetErrorString(_e)); } while (0)
+
+struct sumo_engine {
+  int device, N;
+  std::vector<char> blob;
+  sumo_model_t hm;  // host view
+  sumo_model_t dm;  // device view
+  Aux aux;
+  Layout L;
+  Params* d_params = nullptr;
+  void* d_blob = nullptr;
+  int* d_ai = nullptr;
+  double* d_af = nullptr;
+  signed char* d_pic = nullptr;
+  double* d_state = nullptr;
+  int* d_counters = nullptr;
+  uint64_t* d_seeds = nullptr;
+  unsigned long long* d_stats = nullptr;
+  int state_stride, obs_stride, act_stride;
+};
+
+static void quat2mat_h(double* m, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+
+static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& af, std::vector<signed char>& pic) {
+  const sumo_model_t* m = &E->hm;
+  int nb = m->nbody, nv = m->nv;
+  if (nb > WAVE || nv > WAVE || m->njnt > WAVE || m->nq > WAVE) FAIL(-10, "scene too large for one wavefront per env (nbody %d nv %d)", nb, nv);
+  if (m->nagent != 2) FAIL(-11, "exactly two agents expected");
+  const int* parent = SUMO_I(m, body_parentid);
+  std::vector<int> depth(nb, 0);
+  int ndepth = 1;
+  for (int b = 1; b < nb; b++) { depth[b] = depth[parent[b]] + 1; if (depth[b] + 1 > ndepth) ndepth = depth[b] + 1; }
+  Aux& A = E->aux;
+  A.ndepth = ndepth;
+  auto push_tbl = [&](const std::vector<int>& v) { int o = (int)ai.size(); ai.insert(ai.end(), v.begin(), v.end()); return o; };
+  std::vector<int> lvl_adr(ndepth + 1, 0), lvl_body;
+  for (int d = 0; d < ndepth; d++) { lvl_adr[d] = (int)lvl_body.size(); for (int b = 0; b < nb; b++) if (depth[b] == d) lvl_body.push_back(b); }
+  lvl_adr[ndepth] = (int)lvl_body.size();
+  std::vector<int> child_adr(nb + 1, 0), child;
+  for (int b = 0; b < nb; b++) { child_adr[b] = (int)child.size(); for (int ch = nb - 1; ch > b; ch--) if (parent[ch] == b && b != 0) child.push_back(ch); }
+  child_adr[nb] = (int)child.size();
+  std::vector<int> chain_len(nb, 0), chain(nb * MAXCHAIN, -1), bchain_len(nb, 0), bchain(nb * MAXBCHAIN, -1), body_agent(nb, -1);
+  pic.assign((size_t)nb * nv, -1);
+  const int* dofnum = SUMO_I(m, body_dofnum);
+  const int* dofadr = SUMO_I(m, body_dofadr);
+  const int* dpar = SUMO_I(m, dof_parentid);
+  for (int b = 1; b < nb; b++) {
+    std::vector<int> bc;
+    for (int k = b; k != 0; k = parent[k]) bc.insert(bc.begin(), k);
+    if ((int)bc.size() > MAXBCHAIN) FAIL(-12, "kinematic tree deeper than %d bodies", MAXBCHAIN);
+    bchain_len[b] = (int)bc.size();
+    for (size_t i = 0; i < bc.size(); i++) bchain[b * MAXBCHAIN + i] = bc[i];
+    int bb = b;
+    while (bb && dofnum[bb] == 0) bb = parent[bb];
+    std::vector<int> dc;
+    if (bb) for (int d = dofadr[bb] + dofnum[bb] - 1; d >= 0; d = dpar[d]) dc.insert(dc.begin(), d);
+    if ((int)dc.size() > MAXCHAIN) FAIL(-13, "dof chain longer than %d", MAXCHAIN);
+    chain_len[b] = (int)dc.size();
+    for (size_t i = 0; i < dc.size(); i++) { chain[b * MAXCHAIN + i] = dc[i]; pic[(size_t)b * nv + dc[i]] = (signed char)i; }
+    for (int a = 0; a < m->nagent; a++) {
+      int adr = SUMO_I(m, agent_bodyadr)[a];
+      if (b >= adr && b < adr + SUMO_I(m, agent_nbody)[a]) body_agent[b] = a;
+    }
+    if (body_agent[b] < 0) FAIL(-14, "body %d belongs to no agent", b);
+    // one geom per moving body, and its frame is the inertial frame (what the kernel assumes)
+    int g0 = SUMO_I(m, body_geomadr)[b], g1 = SUMO_I(m, body_geomadr)[b + 1];
+    if (g1 - g0 != 1) FAIL(-15, "body %d has %d geoms; the engine needs exactly one per moving body", b, g1 - g0);
+    for (int k = 0; k < 3; k++) if (SUMO_F(m, geom_pos)[3 * g0 + k] != SUMO_F(m, body_ipos)[3 * b + k]) FAIL(-16, "geom/inertial frame mismatch");
+    for (int k = 0; k < 4; k++) if (SUMO_F(m, geom_quat)[4 * g0 + k] != SUMO_F(m, body_iquat)[4 * b + k]) FAIL(-16, "geom/inertial frame mismatch");
+  }
+  // one actuator per dof at most (kernel adds actuator forces without atomics)
+  {
+    std::vector<int> seen(nv, 0);
+    for (int u = 0; u < m->nu; u++) { int d = SUMO_I(m, actuator_dofid)[u]; if (seen[d]++) FAIL(-17, "two actuators on one dof"); }
+  }
+  std::vector<int> tri_i, tri_j;
+  for (int i = 0; i < nv; i++) for (int j = 0; j <= i; j++) { tri_i.push_back(i); tri_j.push_back(j); }
+  A.ntri = (int)tri_i.size();
+  A.o_lvl_adr = push_tbl(lvl_adr); A.o_lvl_body = push_tbl(lvl_body); A.o_child_adr = push_tbl(child_adr);
+  A.o_child = push_tbl(child.empty() ? std::vector<int>(1, 0) : child);
+  A.o_chain_len = push_tbl(chain_len); A.o_chain = push_tbl(chain); A.o_bchain_len = push_tbl(bchain_len);
+  A.o_bchain = push_tbl(bchain); A.o_body_agent = push_tbl(body_agent); A.o_tri_i = push_tbl(tri_i); A.o_tri_j = push_tbl(tri_j);
+  A.o_wgmat = 0;
+  af.assign((size_t)9 * m->ngeom, 0.0);
+  for (int g = 0; g < m->ngeom; g++) quat2mat_h(&af[9 * g], SUMO_F(m, geom_quat) + 4 * g);
+  return 0;
+}
+
+static void build_layout(sumo_engine* E) {
+  const sumo_model_t* m = &E->hm;
+  Layout& L = E->L;
+  int nq = m->nq, nv = m->nv, nb = m->nbody, nj = m->njnt, nu = m->nu;
+  L.ld = nv | 1;
+  int nhinge = 0;
+  for (int j = 0; j < nj; j++) if (SUMO_I(m, jnt_type)[j] == SUMO_JNT_HINGE) nhinge++;
+  L.maxcon = nv <= 28 ? 24 : (nv <= 36 ? 32 : 40);
+  const char* mc = getenv("SUMO_MAXCON");
+  if (mc && atoi(mc) > 0) L.maxcon = atoi(mc);
+  L.maxefc = 4 * L.maxcon + 2 * nhinge;
+  L.maxcand = 128;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += n; return r; };
+  L.qpos = take(nq); L.qvel = take(nv); L.warm = take(nv); L.ctrl = take(nu);
+  L.x0 = take(nq + nv); L.accv = take(nv); L.acca = take(nv); L.tmpv = take(nv);
+  // kinematic scratch (dead once the mass matrix is built) -- H aliases its start
+  int kin0 = o;
+  L.xpos = take(3 * nb); L.xquat = take(4 * nb); L.xipos = take(3 * nb); L.gaxis = take(3 * nb);
+  L.xanchor = take(3 * nj); L.xaxis = take(3 * nj); L.com = take(3 * m->nagent);
+  L.cinert = take(10 * nb); L.cdof = take(6 * nv); L.abuf = take(6 * nb); L.cfrc = take(6 * nb);
+  int kin1 = o;
+  L.H = kin0;
+  if (kin1 - kin0 < nv * L.ld) o = kin0 + nv * L.ld;
+  L.M = take(nv * L.ld); L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = take(nv); L.grad = take(nv);
+  L.search = take(nv); L.Mv = take(nv); L.x = take(nv); L.dlim = take(nv);
+  L.cond = take(14 * L.maxcon); L.Jb = take(48 * L.maxcon); L.cpar = take(4 * L.maxcon); L.cW = take(6 * L.maxcon);
+  L.cp = take(3 * L.maxcon);
+  L.jar = take(L.maxefc); L.Jv = take(L.maxefc); L.D = take(L.maxefc); L.aref = take(L.maxefc);
+  L.i_base = o;
+  int io = 0;
+  auto itake = [&](int n) { int r = io; io += n; return r; };
+  L.con_b = itake(4 * L.maxcon); L.dofidx = itake(16 * L.maxcon); L.plist = itake(L.maxcand);
+  L.lim_dof = itake(2 * nhinge);
+  if (io & 1) io++;
+  L.lim_sign = itake(2 * 2 * nhinge);  // doubles stored in the int region (2 ints each), 8-byte aligned
+  L.scal = itake(8);
+  L.b_slotof = io * 4;
+  int bytes_slot = L.maxcon * nv;
+  L.total_bytes = o * 8 + io * 4 + ((bytes_slot + 15) & ~15);
+}
+
+extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, int device, sumo_handle_t* out) {
+  if (!model_blob || !out || num_envs <= 0) FAIL(-1, "bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) FAIL(-2, "no HIP device available: the engine has no CPU fallback");
+  if (device < 0 || device >= ndev) FAIL(-3, "device %d out of range (%d devices)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  sumo_engine* E = new sumo_engine();
+  E->device = device; E->N = num_envs;
+  E->blob.assign((const char*)model_blob, (const char*)model_blob + nbytes);
+  int rc = sumo_model_parse(&E->hm, E->blob.data(), nbytes);
+  if (rc != 0) { delete E; FAIL(-4, "malformed model blob (%d)", rc); }
+  std::vector<int> ai; std::vector<double> af; std::vector<signed char> pic;
+  rc = build_aux(E, ai, af, pic);
+  if (rc != 0) { delete E; return rc; }
+  build_layout(E);
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if ((size_t)E->L.total_bytes > prop.sharedMemPerBlock && (size_t)E->L.total_bytes > 160 * 1024) {
+    delete E; FAIL(-5, "LDS need %d bytes exceeds the device limit", E->L.total_bytes);
+  }
+  const sumo_model_t* m = &E->hm;
+  int od = 0, ad = 0;
+  for (int a = 0; a < m->nagent; a++) {
+    int o = SUMO_I(m, agent_nq)[a] + SUMO_I(m, agent_nv)[a] + 6 * SUMO_I(m, agent_nbody)[a] + 14;
+    if (o > od) od = o;
+    if (SUMO_I(m, agent_nu)[a] > ad) ad = SUMO_I(m, agent_nu)[a];
+  }
+  E->obs_stride = od; E->act_stride = ad;
+  E->state_stride = (m->nq + 2 * m->nv + 2 + 15) & ~15;
+  HIPCHK(hipMalloc(&E->d_blob, nbytes));
+  HIPCHK(hipMemcpy(E->d_blob, E->blob.data(), nbytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&E->d_ai, ai.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(E->d_ai, ai.data(), ai.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&E->d_af, af.size() * sizeof(double)));
+  HIPCHK(hipMemcpy(E->d_af, af.data(), af.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&E->d_pic, pic.size()));
+  HIPCHK(hipMemcpy(E->d_pic, pic.data(), pic.size(), hipMemcpyHostToDevice));
+  E->aux.ai = E->d_ai; E->aux.af = E->d_af; E->aux.pic = E->d_pic;
+  E->dm = E->hm;
+  E->dm.ibase = (const int32_t*)((const char*)E->d_blob + ((const char*)E->hm.ibase - E->blob.data()));
+  E->dm.fbase = (const double*)((const char*)E->d_blob + ((const char*)E->hm.fbase - E->blob.data()));
+  {
+    Params hp;
+    hp.mdl = E->dm; hp.aux = E->aux; hp.L = E->L;
+    HIPCHK(hipMalloc((void**)&E->d_params, sizeof(Params)));
+    HIPCHK(hipMemcpy(E->d_params, &hp, sizeof(Params), hipMemcpyHostToDevice));
+  }
+  size_t N = (size_t)num_envs;
+  HIPCHK(hipMalloc((void**)&E->d_state, N * E->state_stride * sizeof(double)));
+  HIPCHK(hipMemset(E->d_state, 0, N * E->state_stride * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&E->d_counters, N * 4 * sizeof(int)));
+  HIPCHK(hipMemset(E->d_counters, 0, N * 4 * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&E->d_seeds, N * sizeof(uint64_t)));
+  std::vector<uint64_t> seeds(N);
+  for (size_t i = 0; i < N; i++) seeds[i] = i;
+  HIPCHK(hipMemcpy(E->d_seeds, seeds.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&E->d_stats, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(E->d_stats, 0, 8 * sizeof(unsigned long long)));
+  // qpos = qpos0 for every env until the first reset / set_state
+  {
+    std::vector<double> st(N * E->state_stride, 0.0);
+    for (size_t e = 0; e < N; e++) memcpy(&st[e * E->state_stride], SUMO_F(m, qpos0), m->nq * sizeof(double));
+    HIPCHK(hipMemcpy(E->d_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (E->L.total_bytes > 64 * 1024) {
+    HIPCHK(hipFuncSetAttribute((const void*)sumo_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E->L.total_bytes));
+    HIPCHK(hipFuncSetAttribute((const void*)sumo_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E->L.total_bytes));
+    HIPCHK(hipFuncSetAttribute((const void*)sumo_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E->L.total_bytes));
+  }
+  *out = E;
+  return 0;
+}
+
+extern "C" int sumo_destroy(sumo_handle_t E) {
+  if (!E) return 0;
+  hipSetDevice(E->device);
+  hipFree(E->d_params); hipFree(E->d_blob); hipFree(E->d_ai); hipFree(E->d_af); hipFree(E->d_pic); hipFree(E->d_state);
+  hipFree(E->d_counters); hipFree(E->d_seeds); hipFree(E->d_stats);
+  delete E;
+  return 0;
+}
+
+extern "C" int sumo_dims(sumo_handle_t E, int32_t* o) {
+  if (!E || !o) FAIL(-1, "bad arguments");
+  const sumo_model_t* m = &E->hm;
+  int v[SUMO_NDIMS] = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->npair, m->nagent, E->obs_stride, E->act_stride,
+                       E->L.maxcon, E->L.maxefc, E->L.total_bytes, E->state_stride, 0, 0};
+  memcpy(o, v, sizeof v);
+  return 0;
+}
+
+static StepArgs base_args(sumo_engine* E) {
+  StepArgs a;
+  memset(&a, 0, sizeof a);
+  a.state = E->d_state; a.counters = E->d_counters; a.seeds = E->d_seeds; a.state_stride = E->state_stride;
+  a.stats = E->d_stats; a.obs_stride = E->obs_stride; a.act_stride = E->act_stride; a.N = E->N;
+  return a;
+}
+
+extern "C" int sumo_reset(sumo_handle_t E, const uint64_t* seeds_host, const uint8_t* mask_dev, float* obs_dev, void* stream) {
+  if (!E) FAIL(-1, "bad handle");
+  HIPCHK(hipSetDevice(E->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (seeds_host) {
+    HIPCHK(hipMemcpyAsync(E->d_seeds, seeds_host, (size_t)E->N * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(E->d_counters, 0, (size_t)E->N * 4 * sizeof(int), s));
+  }
+  StepArgs a = base_args(E);
+  a.mask = mask_dev; a.obs = obs_dev;
+  hipLaunchKernelGGL(sumo_reset_kernel, dim3(E->N), dim3(WAVE), E->L.total_bytes, s, E->d_params, a);
+  HIPCHK(hipGetLastError());
+  if (seeds_host) HIPCHK(hipStreamSynchronize(s));  // seeds_host may be freed by the caller after return
+  return 0;
+}
+
+extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_dev, double* info_dev, uint8_t* done_dev,
+                         double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream) {
+  if (!E || !actions_dev || !obs_dev || !info_dev || !done_dev || !ep_r_dev || !ep_dr_dev || !ep_l_dev) FAIL(-1, "bad arguments");
+  HIPCHK(hipSetDevice(E->device));
+  StepArgs a = base_args(E);
+  a.actions = actions_dev; a.obs = obs_dev; a.info = info_dev; a.done = done_dev; a.ep_r = ep_r_dev; a.ep_dr = ep_dr_dev;
+  a.ep_l = ep_l_dev;
+  hipLaunchKernelGGL(sumo_step_kernel, dim3(E->N), dim3(WAVE), E->L.total_bytes, (hipStream_t)stream, E->d_params, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sumo_get_state(sumo_handle_t E, double* qpos, double* qvel, double* warm, int32_t* counters) {
+  if (!E) FAIL(-1, "bad handle");
+  HIPCHK(hipSetDevice(E->device));
+  HIPCHK(hipDeviceSynchronize());
+  const sumo_model_t* m = &E->hm;
+  size_t N = (size_t)E->N;
+  std::vector<double> st(N * E->state_stride);
+  std::vector<int> cn(N * 4);
+  HIPCHK(hipMemcpy(st.data(), E->d_state, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cn.data(), E->d_counters, cn.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < N; e++) {
+    const double* s = &st[e * E->state_stride];
+    if (qpos) memcpy(qpos + e * m->nq, s, m->nq * sizeof(double));
+    if (qvel) memcpy(qvel + e * m->nv, s + m->nq, m->nv * sizeof(double));
+    if (warm) memcpy(warm + e * m->nv, s + m->nq + m->nv, m->nv * sizeof(double));
+    if (counters) { counters[2 * e] = cn[4 * e]; counters[2 * e + 1] = cn[4 * e + 1]; }
+  }
+  return 0;
+}
+
+extern "C" int sumo_set_state(sumo_handle_t E, const double* qpos, const double* qvel, const double* warm, const int32_t* counters) {
+  if (!E) FAIL(-1, "bad handle");
+  HIPCHK(hipSetDevice(E->device));
+  HIPCHK(hipDeviceSynchronize());
+  const sumo_model_t* m = &E->hm;
+  size_t N = (size_t)E->N;
+  std::vector<double> st(N * E->state_stride);
+  std::vector<int> cn(N * 4);
+  HIPCHK(hipMemcpy(st.data(), E->d_state, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cn.data(), E->d_counters, cn.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < N; e++) {
+    double* s = &st[e * E->state_stride];
+    if (qpos) memcpy(s, qpos + e * m->nq, m->nq * sizeof(double));
+    if (qvel) memcpy(s + m->nq, qvel + e * m->nv, m->nv * sizeof(double));
+    if (warm) memcpy(s + m->nq + m->nv, warm + e * m->nv, m->nv * sizeof(double));
+    if (counters) { cn[4 * e] = counters[2 * e]; cn[4 * e + 1] = counters[2 * e + 1]; }
+  }
+  HIPCHK(hipMemcpy(E->d_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(E->d_counters, cn.data(), cn.size() * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int sumo_debug_forward(sumo_handle_t E, const double* ctrl, double* qacc, int32_t* counts) {
+  if (!E || !ctrl || !qacc || !counts) FAIL(-1, "bad arguments");
+  HIPCHK(hipSetDevice(E->device));
+  const sumo_model_t* m = &E->hm;
+  size_t N = (size_t)E->N;
+  double *d_ctrl, *d_qacc;
+  int* d_cnt;
+  HIPCHK(hipMalloc((void**)&d_ctrl, N * m->nu * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&d_qacc, N * m->nv * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&d_cnt, N * 4 * sizeof(int)));
+  HIPCHK(hipMemcpy(d_ctrl, ctrl, N * m->nu * sizeof(double), hipMemcpyHostToDevice));
+  StepArgs a = base_args(E);
+  a.stats = nullptr; a.dbg_ctrl = d_ctrl; a.dbg_qacc = d_qacc; a.dbg_counts = d_cnt;
+  hipLaunchKernelGGL(sumo_forward_kernel, dim3(E->N), dim3(WAVE), E->L.total_bytes, 0, E->d_params, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(qacc, d_qacc, N * m->nv * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(counts, d_cnt, N * 4 * sizeof(int), hipMemcpyDeviceToHost));
+  hipFree(d_ctrl); hipFree(d_qacc); hipFree(d_cnt);
+  return 0;
+}
+
+extern "C" int sumo_stats(sumo_handle_t E, double* out8) {
+  if (!E || !out8) FAIL(-1, "bad arguments");
+  HIPCHK(hipSetDevice(E->device));
+  HIPCHK(hipDeviceSynchronize());
+  unsigned long long h[8];
+  HIPCHK(hipMemcpy(h, E->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; i++) out8[i] = (double)h[i];
+  return 0;
+}
