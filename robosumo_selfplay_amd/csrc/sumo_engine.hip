@@ -511,8 +511,9 @@ __device__ void collision(Ctx& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane, np = mdl.npair;
   int* plist = c.si + c.P->L.plist;
-  // broad phase
-  int ncand = 0;
+  // broad phase over the static pair list; survivors are queued in `plist` (pair order preserved) and the narrow
+  // phase drains the queue whenever another round of 64 could overflow it
+  int ncand = 0, ncon = 0, dropped = 0;
   for (int p0 = 0; p0 < np; p0 += WAVE) {
     int p = p0 + lane, pass = 0;
     if (p < np) {
@@ -532,127 +533,127 @@ __device__ void collision(Ctx& c) {
     }
     unsigned long long bal = __ballot(pass);
     int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
-    if (pass && pos < c.P->L.maxcand) plist[pos] = p;
+    if (pass) plist[pos] = p;
     ncand += __popcll(bal);
-  }
-  if (ncand > c.P->L.maxcand) ncand = c.P->L.maxcand;
-  SYNC();
-  // narrow phase
-  int ncon = 0, dropped = 0;
-  for (int k0 = 0; k0 < ncand; k0 += WAVE) {
-    int k = k0 + lane;
-    Con1 cs[3];
-    cs[0].ok = cs[1].ok = cs[2].ok = 0;
-    int p = 0, b1 = 0, b2 = 0;
-    double margin = 0;
-    if (k < ncand) {
-      p = plist[k];
-      int g1 = MI(pair_geom1)[p], g2 = MI(pair_geom2)[p];
-      int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
-      if (t1 == SUMO_GEOM_CYLINDER) t1 = SUMO_GEOM_CAPSULE;  // border rods as capsules
-      if (t2 == SUMO_GEOM_CYLINDER) t2 = SUMO_GEOM_CAPSULE;
-      b1 = MI(geom_bodyid)[g1]; b2 = MI(geom_bodyid)[g2];
-      margin = MF(pair_margin)[p];
-      const double* s1 = MF(geom_size) + 3 * g1;
-      const double* s2 = MF(geom_size) + 3 * g2;
-      double p1[3], p2[3], a1[3], a2[3];
-      geom_center(c, g1, p1);
-      geom_center(c, g2, p2);
-      if (t1 == SUMO_GEOM_PLANE) {
-        geom_axis(c, g1, a1);
-        if (t2 == SUMO_GEOM_SPHERE) plane_sphere(cs[0], margin, p1, a1, p2, s2[0]);
-        else if (t2 == SUMO_GEOM_CAPSULE) {
-          geom_axis(c, g2, a2);
-          double e[3];
-          for (int q = 0; q < 3; q++) e[q] = p2[q] + a2[q] * s2[1];
-          plane_sphere(cs[0], margin, p1, a1, e, s2[0]);
-          for (int q = 0; q < 3; q++) e[q] = p2[q] - a2[q] * s2[1];
-          plane_sphere(cs[1], margin, p1, a1, e, s2[0]);
-        }
-      } else if (t1 == SUMO_GEOM_SPHERE && t2 == SUMO_GEOM_SPHERE) {
-        sphere_sphere(cs[0], margin, p1, s1[0], p2, s2[0]);
-      } else if (t1 == SUMO_GEOM_SPHERE && t2 == SUMO_GEOM_CAPSULE) {
-        geom_axis(c, g2, a2);
-        double v[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-        double x = dot3(a2, v);
-        if (x > s2[1]) x = s2[1];
-        if (x < -s2[1]) x = -s2[1];
-        double e[3] = {p2[0] + a2[0] * x, p2[1] + a2[1] * x, p2[2] + a2[2] * x};
-        sphere_sphere(cs[0], margin, p1, s1[0], e, s2[0]);
-      } else if (t1 == SUMO_GEOM_CAPSULE && t2 == SUMO_GEOM_CAPSULE) {
-        geom_axis(c, g1, a1);
-        geom_axis(c, g2, a2);
-        for (int q = 0; q < 3; q++) { a1[q] *= s1[1]; a2[q] *= s2[1]; }
-        double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-        double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
-        double det = ma * mc - mb * mb, v1[3], v2[3];
-        if (fabs(det) >= MINVAL) {
-          double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
-          if (x1 > 1) { x1 = 1; x2 = (v - mb) / mc; }
-          else if (x1 < -1) { x1 = -1; x2 = (v + mb) / mc; }
-          if (x2 > 1) { x2 = 1; x1 = (u - mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
-          else if (x2 < -1) { x2 = -1; x1 = (u + mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
-          for (int q = 0; q < 3; q++) { v1[q] = p1[q] + a1[q] * x1; v2[q] = p2[q] + a2[q] * x2; }
-          sphere_sphere(cs[0], margin, v1, s1[0], v2, s2[0]);
-        } else {
-          for (int si = 0; si < 2; si++) {
-            double s = si == 0 ? 1.0 : -1.0;
-            double x2 = (v - s * mb) / mc;
-            if (x2 > 1) x2 = 1; else if (x2 < -1) x2 = -1;
-            for (int q = 0; q < 3; q++) { v1[q] = p1[q] + s * a1[q]; v2[q] = p2[q] + a2[q] * x2; }
-            if (si == 0) sphere_sphere(cs[0], margin, v1, s1[0], v2, s2[0]);
-            else sphere_sphere(cs[1], margin, v1, s1[0], v2, s2[0]);
-          }
-        }
-      } else if (t2 == SUMO_GEOM_BOX) {
-        const double* bm = c.P->aux.af + c.P->aux.o_wgmat + 9 * g2;
-        if (t1 == SUMO_GEOM_SPHERE) sphere_box(cs[0], margin, p1, s1[0], p2, bm, s2);
-        else if (t1 == SUMO_GEOM_CAPSULE) {
+    if (ncand + WAVE <= c.P->L.maxcand && p0 + WAVE < np) continue;
+    SYNC();
+    for (int k0 = 0; k0 < ncand; k0 += WAVE) {
+      int k = k0 + lane;
+      Con1 cs[3];
+      cs[0].ok = cs[1].ok = cs[2].ok = 0;
+      int p = 0, b1 = 0, b2 = 0;
+      double margin = 0;
+      if (k < ncand) {
+        p = plist[k];
+        int g1 = MI(pair_geom1)[p], g2 = MI(pair_geom2)[p];
+        int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
+        if (t1 == SUMO_GEOM_CYLINDER) t1 = SUMO_GEOM_CAPSULE;  // border rods as capsules
+        if (t2 == SUMO_GEOM_CYLINDER) t2 = SUMO_GEOM_CAPSULE;
+        b1 = MI(geom_bodyid)[g1]; b2 = MI(geom_bodyid)[g2];
+        margin = MF(pair_margin)[p];
+        const double* s1 = MF(geom_size) + 3 * g1;
+        const double* s2 = MF(geom_size) + 3 * g2;
+        double p1[3], p2[3], a1[3], a2[3];
+        geom_center(c, g1, p1);
+        geom_center(c, g2, p2);
+        if (t1 == SUMO_GEOM_PLANE) {
           geom_axis(c, g1, a1);
-          double axw[3] = {a1[0] * s1[1], a1[1] * s1[1], a1[2] * s1[1]}, e[3];
-          for (int q = 0; q < 3; q++) e[q] = p1[q] + axw[q];
-          sphere_box(cs[0], margin, e, s1[0], p2, bm, s2);
-          for (int q = 0; q < 3; q++) e[q] = p1[q] - axw[q];
-          sphere_box(cs[1], margin, e, s1[0], p2, bm, s2);
-          double t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, cc[3], a[3];
-          mulmatTvec3(cc, bm, t);
-          mulmatTvec3(a, bm, axw);
-          double glo = seg_box_dgrad(cc, a, s2, -1.0), ghi = seg_box_dgrad(cc, a, s2, 1.0);
-          if (glo < 0 && ghi > 0) {
-            double lo = -1, hi = 1;
-            for (int it = 0; it < SEGBOX_BISECT; it++) {
-              double mid = 0.5 * (lo + hi);
-              if (seg_box_dgrad(cc, a, s2, mid) > 0) hi = mid; else lo = mid;
+          if (t2 == SUMO_GEOM_SPHERE) plane_sphere(cs[0], margin, p1, a1, p2, s2[0]);
+          else if (t2 == SUMO_GEOM_CAPSULE) {
+            geom_axis(c, g2, a2);
+            double e[3];
+            for (int q = 0; q < 3; q++) e[q] = p2[q] + a2[q] * s2[1];
+            plane_sphere(cs[0], margin, p1, a1, e, s2[0]);
+            for (int q = 0; q < 3; q++) e[q] = p2[q] - a2[q] * s2[1];
+            plane_sphere(cs[1], margin, p1, a1, e, s2[0]);
+          }
+        } else if (t1 == SUMO_GEOM_SPHERE && t2 == SUMO_GEOM_SPHERE) {
+          sphere_sphere(cs[0], margin, p1, s1[0], p2, s2[0]);
+        } else if (t1 == SUMO_GEOM_SPHERE && t2 == SUMO_GEOM_CAPSULE) {
+          geom_axis(c, g2, a2);
+          double v[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+          double x = dot3(a2, v);
+          if (x > s2[1]) x = s2[1];
+          if (x < -s2[1]) x = -s2[1];
+          double e[3] = {p2[0] + a2[0] * x, p2[1] + a2[1] * x, p2[2] + a2[2] * x};
+          sphere_sphere(cs[0], margin, p1, s1[0], e, s2[0]);
+        } else if (t1 == SUMO_GEOM_CAPSULE && t2 == SUMO_GEOM_CAPSULE) {
+          geom_axis(c, g1, a1);
+          geom_axis(c, g2, a2);
+          for (int q = 0; q < 3; q++) { a1[q] *= s1[1]; a2[q] *= s2[1]; }
+          double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+          double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
+          double det = ma * mc - mb * mb, v1[3], v2[3];
+          if (fabs(det) >= MINVAL) {
+            double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+            if (x1 > 1) { x1 = 1; x2 = (v - mb) / mc; }
+            else if (x1 < -1) { x1 = -1; x2 = (v + mb) / mc; }
+            if (x2 > 1) { x2 = 1; x1 = (u - mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
+            else if (x2 < -1) { x2 = -1; x1 = (u + mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
+            for (int q = 0; q < 3; q++) { v1[q] = p1[q] + a1[q] * x1; v2[q] = p2[q] + a2[q] * x2; }
+            sphere_sphere(cs[0], margin, v1, s1[0], v2, s2[0]);
+          } else {
+            for (int si = 0; si < 2; si++) {
+              double s = si == 0 ? 1.0 : -1.0;
+              double x2 = (v - s * mb) / mc;
+              if (x2 > 1) x2 = 1; else if (x2 < -1) x2 = -1;
+              for (int q = 0; q < 3; q++) { v1[q] = p1[q] + s * a1[q]; v2[q] = p2[q] + a2[q] * x2; }
+              if (si == 0) sphere_sphere(cs[0], margin, v1, s1[0], v2, s2[0]);
+              else sphere_sphere(cs[1], margin, v1, s1[0], v2, s2[0]);
             }
-            double ts = 0.5 * (lo + hi);
-            for (int q = 0; q < 3; q++) e[q] = p1[q] + ts * axw[q];
-            sphere_box(cs[2], margin, e, s1[0], p2, bm, s2);
+          }
+        } else if (t2 == SUMO_GEOM_BOX) {
+          const double* bm = c.P->aux.af + c.P->aux.o_wgmat + 9 * g2;
+          if (t1 == SUMO_GEOM_SPHERE) sphere_box(cs[0], margin, p1, s1[0], p2, bm, s2);
+          else if (t1 == SUMO_GEOM_CAPSULE) {
+            geom_axis(c, g1, a1);
+            double axw[3] = {a1[0] * s1[1], a1[1] * s1[1], a1[2] * s1[1]}, e[3];
+            for (int q = 0; q < 3; q++) e[q] = p1[q] + axw[q];
+            sphere_box(cs[0], margin, e, s1[0], p2, bm, s2);
+            for (int q = 0; q < 3; q++) e[q] = p1[q] - axw[q];
+            sphere_box(cs[1], margin, e, s1[0], p2, bm, s2);
+            double t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, cc[3], a[3];
+            mulmatTvec3(cc, bm, t);
+            mulmatTvec3(a, bm, axw);
+            double glo = seg_box_dgrad(cc, a, s2, -1.0), ghi = seg_box_dgrad(cc, a, s2, 1.0);
+            if (glo < 0 && ghi > 0) {
+              double lo = -1, hi = 1;
+              for (int it = 0; it < SEGBOX_BISECT; it++) {
+                double mid = 0.5 * (lo + hi);
+                if (seg_box_dgrad(cc, a, s2, mid) > 0) hi = mid; else lo = mid;
+              }
+              double ts = 0.5 * (lo + hi);
+              for (int q = 0; q < 3; q++) e[q] = p1[q] + ts * axw[q];
+              sphere_box(cs[2], margin, e, s1[0], p2, bm, s2);
+            }
           }
         }
       }
-    }
-    int act[3], n = 0;
-#pragma unroll
-    for (int q = 0; q < 3; q++) { act[q] = cs[q].ok && (cs[q].dist < margin); n += act[q]; }
-    int total, base = wave_excl_scan(n, lane, &total);
-    int slot = ncon + base;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      if (act[q]) {
-        if (slot < c.P->L.maxcon) {
-          double* cd = S(cond) + 14 * slot;
-          double fr[9] = {cs[q].nrm[0], cs[q].nrm[1], cs[q].nrm[2], 0, 0, 0, 0, 0, 0};
-          make_frame(fr);
-          cd[0] = cs[q].dist; cd[1] = cs[q].pos[0]; cd[2] = cs[q].pos[1]; cd[3] = cs[q].pos[2];
-          for (int w = 0; w < 9; w++) cd[4 + w] = fr[w];
-          cd[13] = 0;
-          int* cb = c.si + c.P->L.con_b + 4 * slot;
-          cb[0] = b1; cb[1] = b2; cb[2] = p; cb[3] = 0;
+      int act[3], n = 0;
+  #pragma unroll
+      for (int q = 0; q < 3; q++) { act[q] = cs[q].ok && (cs[q].dist < margin); n += act[q]; }
+      int total, base = wave_excl_scan(n, lane, &total);
+      int slot = ncon + base;
+  #pragma unroll
+      for (int q = 0; q < 3; q++) {
+        if (act[q]) {
+          if (slot < c.P->L.maxcon) {
+            double* cd = S(cond) + 14 * slot;
+            double fr[9] = {cs[q].nrm[0], cs[q].nrm[1], cs[q].nrm[2], 0, 0, 0, 0, 0, 0};
+            make_frame(fr);
+            cd[0] = cs[q].dist; cd[1] = cs[q].pos[0]; cd[2] = cs[q].pos[1]; cd[3] = cs[q].pos[2];
+            for (int w = 0; w < 9; w++) cd[4 + w] = fr[w];
+            cd[13] = 0;
+            int* cb = c.si + c.P->L.con_b + 4 * slot;
+            cb[0] = b1; cb[1] = b2; cb[2] = p; cb[3] = 0;
+          }
+          slot++;
         }
-        slot++;
       }
+      ncon += total;
     }
-    ncon += total;
+    ncand = 0;
+    SYNC();
   }
   if (ncon > c.P->L.maxcon) { dropped = ncon - c.P->L.maxcon; ncon = c.P->L.maxcon; }
   c.ncon = ncon;
@@ -1439,7 +1440,7 @@ static void build_layout(sumo_engine* E) {
   const char* mc = getenv("SUMO_MAXCON");
   if (mc && atoi(mc) > 0) L.maxcon = atoi(mc);
   L.maxefc = 4 * L.maxcon + 2 * nhinge;
-  L.maxcand = 128;
+  L.maxcand = 128;  // queue of broad-phase survivors, drained by the narrow phase before it can overflow
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
   L.qpos = take(nq); L.qvel = take(nv); L.warm = take(nv); L.ctrl = take(nu);

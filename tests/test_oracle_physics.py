@@ -1,0 +1,280 @@
+"""The CPU oracle is the checker for the HIP path, so it is pinned here against everything that CAN be pinned
+offline: (i) the reference's own game logic (sumo.py / agents.py / sumo_env.py / subproc_vec_env.py, cited per
+test), restated independently in numpy below; (ii) physics invariants and known answers.
+MuJoCo trajectories themselves cannot be pinned (no binary, no fixtures in the reference): parity unpinned."""
+import math
+
+import numpy as np
+import pytest
+
+from robosumo_selfplay_amd import mjcf
+
+G = 9.81
+
+
+def _settled(oracle_lib, model, N=2, steps=60, seed=3):
+    sim = oracle_lib.OracleSim(model, N)
+    sim.reset(seeds=np.arange(N) + seed)
+    z = np.zeros((N, 2, sim.act_stride), np.float32)
+    for _ in range(steps):
+        sim.step(z, nthreads=4)
+    return sim
+
+
+def test_mass_matrix_matches_jacobian_formulation(ant_model, spider_model, oracle_lib):
+    for m in (ant_model, spider_model):
+        sim = oracle_lib.OracleSim(m, 1)
+        sim.reset(seeds=[11])
+        qpos = sim.get_state()[0][0]
+        sim.forward(0, np.zeros(m.nu))
+        M = sim.array("M").reshape(m.nv, m.nv)
+        Mnp, _, _ = mjcf.mass_matrix_np(m, qpos)
+        assert np.abs(M - Mnp).max() < 1e-12
+
+
+def test_free_flight_momentum(ant_model, oracle_lib):
+    """No contacts, no active limits: each agent's linear momentum changes by exactly -m*g*h per mj_step in z and
+    not at all in x, y (momentum = translational rows of M times qvel)."""
+    m = ant_model
+    sim = oracle_lib.OracleSim(m, 1)
+    rng = np.random.default_rng(7)
+    q = m.qpos0.copy()[None]
+    q[0, 2] = q[0, 17] = 3.0
+    for a in range(2):
+        quat = rng.standard_normal(4)
+        q[0, 15 * a + 3:15 * a + 7] = quat / np.linalg.norm(quat)
+        for k in range(8):                       # mid-range of every hinge -> no limit rows
+            lo, hi = m.jnt_range[1 + 9 * a + k]
+            q[0, 15 * a + 7 + k] = 0.5 * (lo + hi)
+    v = rng.standard_normal((1, m.nv)) * 0.5
+    sim.set_state(q, v, np.zeros((1, m.nv)), np.zeros((1, 2), np.int32))
+
+    def momentum(qq, vv):
+        M, _, _ = mjcf.mass_matrix_np(m, qq)
+        Mv = M @ vv
+        return np.stack([Mv[0:3], Mv[14:17]])
+    p0 = momentum(q[0], v[0])
+    sim.mj_step(0, np.zeros(m.nu), 1)
+    assert sim.array("counts")[0] == 0 and sim.array("counts")[1] == 0
+    q1, v1, _, _ = sim.get_state()
+    p1 = momentum(q1[0], v1[0])
+    mass = m.body_mass[1:14].sum()
+    assert np.allclose(p1[:, :2], p0[:, :2], atol=1e-7)
+    assert np.allclose(p1[:, 2] - p0[:, 2], -mass * G * 0.01, rtol=1e-5)
+
+
+def test_resting_contact_supports_weight(ant_model, oracle_lib):
+    sim = _settled(oracle_lib, ant_model, N=2, steps=120)
+    q, v, _, _ = sim.get_state()
+    assert np.abs(v).max() < 0.3
+    sim.forward(0, np.zeros(ant_model.nu))
+    qc = sim.array("qfrc_constraint")
+    mg = ant_model.body_mass[1:14].sum() * G
+    assert qc[2] == pytest.approx(mg, rel=5e-2) and qc[16] == pytest.approx(mg, rel=5e-2)
+    f = sim.array("efc_force")
+    assert np.all(f >= 0)
+    # tatami top is z=0.5; standing ants keep their torso well above it
+    assert 0.6 < q[0, 2] < 1.3
+
+
+def test_joint_limit_pushes_back(ant_model, oracle_lib):
+    m = ant_model
+    sim = oracle_lib.OracleSim(m, 1)
+    q = m.qpos0.copy()[None]
+    q[0, 2] = 5.0
+    q[0, 17] = 5.0                     # far from everything
+    q[0, 7] = np.deg2rad(45.0)         # hip_1 range is +-30 deg -> upper limit violated
+    sim.set_state(q, np.zeros((1, m.nv)), np.zeros((1, m.nv)), np.zeros((1, 2), np.int32))
+    sim.forward(0, np.zeros(m.nu))
+    J = sim.array("efc_J").reshape(-1, m.nv)
+    f = sim.array("efc_force")
+    rows = np.nonzero(J[:, 6])[0]
+    assert len(rows) == 1 and J[rows[0], 6] == -1.0 and f[rows[0]] > 0
+    assert sim.array("qfrc_constraint")[6] < 0
+
+
+def test_agent_swap_symmetry(ant_model, oracle_lib):
+    """Exchanging the two (identical) agents' states and actions exchanges their outputs."""
+    m = ant_model
+    sim = _settled(oracle_lib, m, N=1, steps=20, seed=9)
+    q, v, w, c = sim.get_state()
+    sw = lambda x, n: np.concatenate([x[:, n:], x[:, :n]], axis=1)
+    sim2 = oracle_lib.OracleSim(m, 1)
+    sim2.set_state(sw(q, 15), sw(v, 14), sw(w, 14), c)
+    a = np.random.default_rng(0).standard_normal((1, 2, 8)).astype(np.float32)
+    o1, i1, d1, *_ = sim.step(a)
+    o2, i2, d2, *_ = sim2.step(a[:, ::-1])
+    assert np.allclose(o1[:, 0], o2[:, 1], atol=1e-5) and np.allclose(o1[:, 1], o2[:, 0], atol=1e-5)
+    assert np.allclose(i1[:, 0], i2[:, 1], atol=1e-7)
+
+
+def _expected_info(model, q_before, q_after, act, num_steps_after):
+    """numpy restatement of sumo.py:120-202 + agents.py:216-223 for one env."""
+    aq = model.agent_qposadr
+    dt = model.opt[0] * model.frame_skip                                 # mujoco_env.py:121-123
+    lim = model.tatami_size + 0.1                                          # sumo.py:55
+    out = np.zeros((2, 8))
+    lost = []
+    for a in range(2):
+        x, y, z = q_after[aq[a]:aq[a] + 3]
+        lost.append(z < 0.29 or max(abs(x), abs(y)) >= lim)               # sumo.py:149-152
+    done = False
+    for a in range(2):
+        o = 1 - a
+        # float32 pairwise sum, then float64 product: numpy 1.18 (the reference's pin, requirements.txt) promotes
+        # python-float * float32-scalar to float64; numpy >= 2 would not, hence the explicit float()
+        ctrl = -0.1 * float(np.square(act[a]).sum())
+        lose = -2000.0 if lost[a] else 0.0
+        win = 2000.0 if lost[o] else 0.0
+        main = win + lose
+        done |= lost[a] or lost[o]
+        if num_steps_after > model.timestep_limit:                         # sumo.py:165-167
+            main += -1000.0
+            done = True
+        pb, pa, oa = q_before[aq[a]:aq[a] + 2], q_after[aq[a]:aq[a] + 2], q_after[aq[o]:aq[o] + 2]
+        mv = (pa - pb) / dt
+        direction = oa - pb
+        direction = direction / np.linalg.norm(direction)
+        move = max(np.sum(mv * direction), 0.0) * 0.1                      # sumo.py:194-198
+        push = -10.0 * np.exp(-np.linalg.norm(oa))                         # sumo.py:200-202
+        out[a, :7] = [ctrl, lose, win, main, move, push, float(ctrl) + push + move]
+        out[a, 7] = 1.0 if lost[o] else 0.0
+    return out, done
+
+
+def test_rewards_and_info_follow_sumo_py(ant_model, oracle_lib):
+    m = ant_model
+    N = 6
+    sim = oracle_lib.OracleSim(m, N)
+    sim.reset(seeds=np.arange(N) + 40)
+    rng = np.random.default_rng(2)
+    for t in range(25):
+        qb = sim.get_state()[0]
+        cnt = sim.get_state()[3]
+        act = rng.standard_normal((N, 2, 8)).astype(np.float32)
+        obs, info, done, ep_r, ep_dr, ep_l = sim.step(act)
+        qa = sim.get_state()[0]
+        for e in range(N):
+            if done[e, 0]:
+                continue  # state was replaced by the reset state; terminal cases are covered below
+            exp, d = _expected_info(m, qb[e], qa[e], act[e], cnt[e, 0] + 1)
+            assert not d
+            assert np.allclose(info[e], exp, rtol=1e-12, atol=1e-12)
+            # observation layout agents.py:190-214 + time feature sumo_env.py:68-70
+            for a in range(2):
+                o = 1 - a
+                ob = obs[e, a]
+                assert np.array_equal(ob[:15], qa[e, 15 * a:15 * a + 15].astype(np.float32))
+                assert np.array_equal(ob[107:114], qa[e, 15 * o:15 * o + 7].astype(np.float32))
+                assert np.all(ob[29:107] == 0) and np.all(ob[114:120] == 0)
+                assert ob[120] == np.float32(-1.0 + 2.0 * (cnt[e, 0] + 1) / 500.0)
+
+
+def test_terminal_win_lose_and_autoreset(ant_model, oracle_lib):
+    m = ant_model
+    sim = _settled(oracle_lib, m, N=1, steps=30)
+    q, v, w, c = sim.get_state()
+    q[0, 0], q[0, 1] = 2.6, 0.0              # agent 0 far outside the ring (|x| >= 2.1) -> loses
+    sim.set_state(q, v, w, c)
+    obs, info, done, ep_r, ep_dr, ep_l = sim.step(np.zeros((1, 2, 8), np.float32))
+    assert done.tolist() == [[1, 1]]
+    assert info[0, 0, 1] == -2000 and info[0, 0, 2] == 0 and info[0, 0, 3] == -2000 and info[0, 0, 7] == 0
+    assert info[0, 1, 1] == 0 and info[0, 1, 2] == 2000 and info[0, 1, 3] == 2000 and info[0, 1, 7] == 1   # 'winner'
+    assert ep_l[0] == 31
+    # auto-reset (subproc_vec_env.py:13-16): reset observation, counters cleared, fresh placement at r=1.15
+    assert obs[0, 0, 120] == -1.0 and obs[0, 1, 120] == -1.0
+    q2, v2, w2, c2 = sim.get_state()
+    assert c2[0, 0] == 0 and c2[0, 1] == c[0, 1] + 1 and np.all(w2 == 0)
+    assert abs(math.hypot(q2[0, 0], q2[0, 1]) - 1.15) < 0.15 and abs(q2[0, 2] - 1.25) <= 0.1
+    assert np.allclose(np.linalg.norm(q2[0, 3:7]), 1.0) and np.allclose(np.linalg.norm(q2[0, 18:22]), 1.0)
+    # the two agents start opposite each other (sumo.py:238-241), up to the +-0.1 noise
+    assert np.allclose(q2[0, 0:2], -q2[0, 15:17], atol=0.2 + 1e-9)
+
+
+def test_draw_penalty_and_timeout_flag(ant_model, oracle_lib):
+    m = ant_model
+    sim = _settled(oracle_lib, m, N=1, steps=10)
+    q, v, w, c = sim.get_state()
+    c[0, 0] = 500                              # next step makes _num_steps 501 > timestep_limit (sumo.py:165)
+    sim.set_state(q, v, w, c)
+    obs, info, done, ep_r, ep_dr, ep_l = sim.step(np.zeros((1, 2, 8), np.float32))
+    assert done[0, 0] == 1 and info[0, 0, 3] == -1000 and info[0, 1, 3] == -1000
+    assert int(info[0, 0, 7]) & 2 and int(info[0, 1, 7]) & 2          # 'timeout' (sumo_env.py:62-65)
+    assert ep_l[0] == 501
+    c[0, 0] = 499
+    sim2 = oracle_lib.OracleSim(m, 1)
+    sim2.set_state(q, v, w, c)
+    _, info2, done2, *_ = sim2.step(np.zeros((1, 2, 8), np.float32))
+    assert done2[0, 0] == 0 and info2[0, 0, 3] == 0
+
+
+def test_episode_return_is_sum_of_agent0_rewards(ant_model, oracle_lib):
+    """monitor.py:56-78 / sumo_env.py:44-58: 'r' sums reward[0] = main+shaping of agent 0, 'dr' the shaping part."""
+    m = ant_model
+    sim = oracle_lib.OracleSim(m, 3)
+    sim.reset(seeds=[1, 2, 3])
+    rng = np.random.default_rng(0)
+    acc = np.zeros(3)
+    accd = np.zeros(3)
+    seen = 0
+    for t in range(200):
+        obs, info, done, ep_r, ep_dr, ep_l = sim.step(rng.standard_normal((3, 2, 8)).astype(np.float32) * 2)
+        acc += info[:, 0, 3] + info[:, 0, 6]
+        accd += info[:, 0, 6]
+        for e in range(3):
+            if done[e, 0]:
+                assert ep_r[e] == pytest.approx(acc[e], rel=1e-12) and ep_dr[e] == pytest.approx(accd[e], rel=1e-12)
+                acc[e] = accd[e] = 0
+                seen += 1
+    assert seen > 0
+
+
+@pytest.mark.parametrize("env_id,n", [("RoboSumo-Ant-vs-Ant-v0", 8), ("RoboSumo-Bug-vs-Bug-v0", 12),
+                                      ("RoboSumo-Spider-vs-Spider-v0", 16)])
+def test_ctrl_reward_float32_pairwise(oracle_lib, env_id, n):
+    m = mjcf.load_model(env_id)
+    sim = oracle_lib.OracleSim(m, 4)
+    sim.reset(seeds=[1, 2, 3, 4])
+    act = (np.random.default_rng(5).standard_normal((4, 2, n)) * 3).astype(np.float32)
+    _, info, *_ = sim.step(act)
+    for e in range(4):
+        for a in range(2):
+            assert info[e, a, 0] == -0.1 * float(np.square(act[e, a]).sum())
+
+
+def test_reset_distribution(ant_model, oracle_lib):
+    """sumo.py:232-253: radius 1.15, z 1.25, opposite placement, U(-.1,.1) position noise, .1*N(0,1) velocity noise."""
+    m = ant_model
+    N = 512
+    sim = oracle_lib.OracleSim(m, N)
+    obs = sim.reset(seeds=np.arange(N))
+    q, v, w, c = sim.get_state()
+    assert np.all(c[:, 0] == 0) and np.all(c[:, 1] == 1) and np.all(w == 0)
+    phi = np.arctan2(q[:, 1], q[:, 0])
+    # heading uniform on the circle: all quadrants populated roughly equally
+    hist = np.histogram(phi, bins=4, range=(-np.pi, np.pi))[0]
+    assert hist.min() > N / 4 * 0.6
+    hinge = np.r_[7:15, 22:30]
+    assert np.all(np.abs(q[:, hinge]) <= 0.1) and q[:, hinge].std() == pytest.approx(0.2 / math.sqrt(12), rel=0.1)
+    assert np.all(np.abs(q[:, 2] - 1.25) <= 0.1)
+    assert v.std() == pytest.approx(0.1, rel=0.05) and abs(v.mean()) < 0.01
+    assert np.allclose(np.linalg.norm(q[:, 3:7], axis=1), 1.0)
+    # streams differ per seed and per reset index, and are reproducible
+    sim2 = oracle_lib.OracleSim(m, N)
+    sim2.reset(seeds=np.arange(N))
+    assert np.array_equal(sim2.get_state()[0], q)
+    sim2.reset()
+    assert not np.allclose(sim2.get_state()[0], q)
+
+
+def test_maxcon_cap_drops_in_order(spider_model, oracle_lib):
+    sim = _settled(oracle_lib, spider_model, N=1, steps=40)
+    sim.forward(0, np.zeros(spider_model.nu))
+    ncon = int(sim.array("counts")[0])
+    assert ncon >= 4
+    full = sim.array("contacts").reshape(-1, 9)
+    capped = oracle_lib.OracleSim(spider_model, 1, maxcon=ncon - 2)
+    capped.set_state(*sim.get_state())
+    capped.forward(0, np.zeros(spider_model.nu))
+    cc = capped.array("contacts").reshape(-1, 9)
+    assert len(cc) == ncon - 2 and np.array_equal(cc, full[:ncon - 2]) and capped.array("counts")[2] == 2
