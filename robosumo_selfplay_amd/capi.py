@@ -22,7 +22,7 @@ class SumoHipError(RuntimeError):
 def lib():
     global _LIB
     if _LIB is None:
-        path = _build.lib_path("libsumo_hip.so")
+        path = os.environ.get("SUMO_HIP_LIB") or _build.lib_path("libsumo_hip.so")  # override: profiling builds
         if not os.path.exists(path):
             raise SumoHipError("%s not found: build it with `python -m robosumo_selfplay_amd.build` "
                                "(the HIP engine has no CPU fallback)" % path)
@@ -38,6 +38,8 @@ def lib():
         L.sumo_set_state.argtypes = [vp] * 5
         L.sumo_debug_forward.argtypes = [vp] * 4
         L.sumo_stats.argtypes = [vp, vp]
+        L.sumo_profile.argtypes = [vp, vp]
+        L.sumo_profile.restype = i32
         for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_get_state",
                   "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
             getattr(L, n).restype = i32
@@ -46,7 +48,7 @@ def lib():
 
 
 EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step",
-           "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats")
+           "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile")
 
 
 def _np(a):
@@ -124,6 +126,11 @@ class Engine:
         counts = np.zeros((self.N, 4), np.int32)
         _chk(lib().sumo_debug_forward(self.h, _np(ctrl), _np(qacc), _np(counts)))
         return qacc, counts
+
+    def profile(self):
+        o = np.zeros(20)
+        _chk(lib().sumo_profile(self.h, _np(o)))
+        return o
 
     def stats(self):
         o = np.zeros(8)

@@ -52,7 +52,7 @@ struct Layout {  // LDS offsets in doubles unless noted
   int qpos, qvel, warm, ctrl, x0, accv, acca, tmpv;
   int xpos, xquat, xipos, gaxis, xanchor, xaxis, com, cinert, cdof, abuf, cfrc;  // "kin scratch"
   int H;                                                                           // aliases kin scratch
-  int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim;
+  int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim, col, dinv;
   int cond, Jb, cpar, cW, cp, jar, Jv, D, aref;
   int i_base;  // start of int region (in doubles)
   // int region offsets (in ints, relative to int base)
@@ -160,19 +160,37 @@ __device__ __forceinline__ void cross_force(double* r, const double* vel, const 
   r[4] = vel[2] * f[3] - vel[0] * f[5];
   r[5] = -vel[1] * f[3] + vel[0] * f[4];
 }
+// DPP move of a double (two 32-bit halves); lanes whose source is out of range / masked read 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+// wave-wide sum, identical bits in every lane (in-row scan with row_shr, then row_bcast 15 / 31, total in lane 63)
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
+  v += dpp_mov_f64<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_mov_f64<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_mov_f64<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_mov_f64<0x118, 0xF>(v);  // row_shr:8
+  v += dpp_mov_f64<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
+  v += dpp_mov_f64<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
+  return readlane_f64(v, 63);
 }
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
   int inc = v;
-#pragma unroll
-  for (int o = 1; o < WAVE; o <<= 1) {
-    int t = __shfl_up(inc, o, WAVE);
-    if (lane >= o) inc += t;
-  }
-  *total = __shfl(inc, WAVE - 1, WAVE);
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);
+  *total = __builtin_amdgcn_readlane(inc, 63);
   return inc - v;
 }
 
@@ -246,7 +264,11 @@ __device__ __forceinline__ double seg_box_dgrad(const double* cc, const double* 
 // ---------------------------------------------------------------------------------------------------------
 struct Params { sumo_model_t mdl; Aux aux; Layout L; };  // lives in device memory; read through scalar loads
 
+template <int NV_>
 struct Ctx {
+  static constexpr int NV = NV_;                                  // compile-time nv (register-resident factorisation)
+  static constexpr int EPL = (NV_ * (NV_ + 1) / 2 + WAVE - 1) / WAVE;
+  unsigned ent[EPL];  // lower-triangle entries assembled by this lane (i << 8 | k), entry t = lane + 64*m; 0xFFFF = none
   const Params* P;
   double* sm;    // LDS base (doubles)
   int* si;       // LDS int region
@@ -254,14 +276,24 @@ struct Ctx {
   int lane;
   // per-forward scalars (wave-uniform)
   int ncon, nlim, nefc, ndropped;
+#ifdef SUMO_PROFILE
+  long long tprev;
+  unsigned long long prof[20];
+#endif
   // statistics accumulated over the launch
   int st_forward, st_newton, st_ncon, st_nefc, st_maxcon, st_maxefc, st_maxnewton, st_dropped;
 };
 
 #define S(off) (c.sm + c.P->L.off)
+#ifdef SUMO_PROFILE
+#define PROF(k) do { long long _t = clock64(); c.prof[k] += (unsigned long long)(_t - c.tprev); c.tprev = _t; } while (0)
+#else
+#define PROF(k) do { } while (0)
+#endif
 
 // ---- position / velocity stage --------------------------------------------------------------------------
-__device__ void kin_body(Ctx& c, int b) {
+template <class C>
+__device__ __forceinline__ void kin_body(C& c, int b) {
   const sumo_model_t& mdl = c.P->mdl;
   double* qpos = S(qpos);
   int pid = MI(body_parentid)[b], ja = MI(body_jntadr)[b], jn = MI(body_jntnum)[b];
@@ -309,7 +341,8 @@ __device__ void kin_body(Ctx& c, int b) {
 }
 
 // gather children into parents, level by level, for an array of `w` doubles per body
-__device__ void gather_up(Ctx& c, double* arr, int w) {
+template <class C>
+__device__ __forceinline__ void gather_up(C& c, double* arr, int w) {
   const Aux& aux = c.P->aux;
   for (int lvl = aux.ndepth - 2; lvl >= 1; lvl--) {
     int a0 = AI(lvl_adr)[lvl], a1 = AI(lvl_adr)[lvl + 1];
@@ -325,7 +358,8 @@ __device__ void gather_up(Ctx& c, double* arr, int w) {
   }
 }
 
-__device__ void position_velocity(Ctx& c) {
+template <class C>
+__device__ __forceinline__ void position_velocity(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const Aux& aux = c.P->aux;
   const int lane = c.lane;
@@ -338,11 +372,13 @@ __device__ void position_velocity(Ctx& c) {
     for (int k = 0; k < 3; k++) { S(xipos)[k] = 0; S(gaxis)[k] = 0; }
   }
   SYNC();
+  PROF(0);
   for (int lvl = 1; lvl < aux.ndepth; lvl++) {
     int a0 = AI(lvl_adr)[lvl], a1 = AI(lvl_adr)[lvl + 1];
     for (int idx = a0 + lane; idx < a1; idx += WAVE) kin_body(c, AI(lvl_body)[idx]);
     SYNC();
   }
+  PROF(1);
   // subtree CoM of each agent's root
   {
     int b = lane;
@@ -407,6 +443,7 @@ __device__ void position_velocity(Ctx& c) {
     }
   }
   SYNC();
+  PROF(2);
   // body velocities along each body's dof chain; a_b = sum over the body's own dofs of cdof_dot * qvel
   double cvel[6] = {0, 0, 0, 0, 0, 0};
   if (lane >= 1 && lane < nb) {
@@ -462,9 +499,11 @@ __device__ void position_velocity(Ctx& c) {
   SYNC();
   gather_up(c, S(cfrc), 6);
   if (lane < nv) S(bias)[lane] = dot6(S(cdof) + 6 * lane, S(cfrc) + 6 * MI(dof_bodyid)[lane]);
+  PROF(3);
 }
 
-__device__ void mass_matrix(Ctx& c) {
+template <class C>
+__device__ __forceinline__ void mass_matrix(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane, nv = mdl.nv, ld = c.P->L.ld;
   gather_up(c, S(cinert), 10);  // cinert -> composite rigid body inertia, in place
@@ -482,20 +521,22 @@ __device__ void mass_matrix(Ctx& c) {
 }
 
 // ---- collision ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void geom_center(const Ctx& c, int g, double* p) {
+template <class C>
+__device__ __forceinline__ void geom_center(const C& c, int g, double* p) {
   const sumo_model_t& mdl = c.P->mdl;
   int b = MI(geom_bodyid)[g];
   if (b == 0) { const double* gp = MF(geom_pos) + 3 * g; p[0] = gp[0]; p[1] = gp[1]; p[2] = gp[2]; }
   else { const double* xp = c.sm + c.P->L.xipos + 3 * b; p[0] = xp[0]; p[1] = xp[1]; p[2] = xp[2]; }
 }
-__device__ __forceinline__ void geom_axis(const Ctx& c, int g, double* a) {
+template <class C>
+__device__ __forceinline__ void geom_axis(const C& c, int g, double* a) {
   const sumo_model_t& mdl = c.P->mdl;
   int b = MI(geom_bodyid)[g];
   if (b == 0) { const double* m = c.P->aux.af + c.P->aux.o_wgmat + 9 * g; a[0] = m[2]; a[1] = m[5]; a[2] = m[8]; }
   else { const double* ga = c.sm + c.P->L.gaxis + 3 * b; a[0] = ga[0]; a[1] = ga[1]; a[2] = ga[2]; }
 }
 
-__device__ void make_frame(double* f) {
+__device__ __forceinline__ void make_frame(double* f) {
   double n2 = sqrt(f[3] * f[3] + f[4] * f[4] + f[5] * f[5]);
   if (n2 < 0.5) {
     f[3] = f[4] = f[5] = 0;
@@ -507,7 +548,8 @@ __device__ void make_frame(double* f) {
   cross3(f + 6, f, f + 3);
 }
 
-__device__ void collision(Ctx& c) {
+template <class C>
+__device__ __forceinline__ void collision(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane, np = mdl.npair;
   int* plist = c.si + c.P->L.plist;
@@ -537,6 +579,7 @@ __device__ void collision(Ctx& c) {
     ncand += __popcll(bal);
     if (ncand + WAVE <= c.P->L.maxcand && p0 + WAVE < np) continue;
     SYNC();
+    PROF(4);
     for (int k0 = 0; k0 < ncand; k0 += WAVE) {
       int k = k0 + lane;
       Con1 cs[3];
@@ -654,6 +697,7 @@ __device__ void collision(Ctx& c) {
     }
     ncand = 0;
     SYNC();
+    PROF(5);
   }
   if (ncon > c.P->L.maxcon) { dropped = ncon - c.P->L.maxcon; ncon = c.P->L.maxcon; }
   c.ncon = ncon;
@@ -691,7 +735,8 @@ __device__ __forceinline__ double row_params(double timestep, const double* solr
   return R < MINVAL ? MINVAL : R;
 }
 
-__device__ void make_constraint(Ctx& c) {
+template <class C>
+__device__ __forceinline__ void make_constraint(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const Aux& aux = c.P->aux;
   const int lane = c.lane, nv = mdl.nv, ncon = c.ncon;
@@ -742,6 +787,7 @@ __device__ void make_constraint(Ctx& c) {
     S(cpar)[4 * ci] = mu;
     for (int k = 0; k < 4; k++) { int r = nlim + 4 * ci + k; S(D)[r] = 1.0 / Rpy; S(Jv)[r] = B; S(jar)[r] = kt; }
   }
+  PROF(6);
   // slot map init
   unsigned char* slotof = c.sb + c.P->L.b_slotof;
   for (int i = lane; i < ncon * nv; i += WAVE) slotof[i] = 0xFF;
@@ -773,10 +819,12 @@ __device__ void make_constraint(Ctx& c) {
     Jb[s] = j0; Jb[16 + s] = j1; Jb[32 + s] = j2;
   }
   SYNC();
+  PROF(7);
 }
 
 // cp[3*c + a] = sum_s Jb[c][a][s] * x[dof(c,s)]
-__device__ void contact_Jx(Ctx& c, const double* x) {
+template <class C>
+__device__ __forceinline__ void contact_Jx(C& c, const double* x) {
   for (int idx = c.lane; idx < 3 * c.ncon; idx += WAVE) {
     int ci = idx / 3, a = idx - 3 * ci;
     const double* Jb = S(Jb) + 48 * ci + 16 * a;
@@ -788,7 +836,8 @@ __device__ void contact_Jx(Ctx& c, const double* x) {
   SYNC();
 }
 // value of row r of J*x given cp (after contact_Jx)
-__device__ __forceinline__ double row_Jx(const Ctx& c, int r, const double* x) {
+template <class C>
+__device__ __forceinline__ double row_Jx(const C& c, int r, const double* x) {
   if (r < c.nlim) return ((const double*)(c.si + c.P->L.lim_sign))[r] * x[(c.si + c.P->L.lim_dof)[r]];
   int q = r - c.nlim, ci = q >> 2, k = q & 3;
   double mu = c.sm[c.P->L.cpar + 4 * ci];
@@ -797,7 +846,8 @@ __device__ __forceinline__ double row_Jx(const Ctx& c, int r, const double* x) {
 }
 
 // y_i = sum_k M[i][k] x[k]   (x in LDS)
-__device__ __forceinline__ double dense_Mx(const Ctx& c, const double* x) {
+template <class C>
+__device__ __forceinline__ double dense_Mx(const C& c, const double* x) {
   double acc = 0;
   if (c.lane < c.P->mdl.nv) {
     const double* row = c.sm + c.P->L.M + c.lane * c.P->L.ld;
@@ -806,47 +856,64 @@ __device__ __forceinline__ double dense_Mx(const Ctx& c, const double* x) {
   return acc;
 }
 
-// in-place Cholesky of the lower triangle of A (LDS, leading dim ld); returns 0 ok (wave-uniform)
-__device__ int cholesky_lds(Ctx& c, double* A, int n) {
-  const int lane = c.lane, ld = c.P->L.ld;
-  int fail = 0;
-  for (int j = 0; j < n; j++) {
-    double s = 0;
-    if (lane >= j && lane < n) {
-      const double* ri = A + lane * ld;
-      const double* rj = A + j * ld;
-      s = ri[j];
-      for (int k = 0; k < j; k++) s -= ri[k] * rj[k];
-    }
-    double sj = __shfl(s, j, WAVE);
-    if (sj < MINVAL) { fail = 1; break; }
-    double d = sqrt(sj);
-    if (lane == j) A[j * ld + j] = d;
-    else if (lane > j && lane < n) A[lane * ld + j] = s / d;
-    SYNC();
-  }
-  return fail;
+__device__ __forceinline__ double fast_rcp(double x) {  // v_rcp_f64 + two Newton steps (~1 ulp)
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
 }
-// solve L L^T x = b; lane i holds b_i on entry and x_i on return
-__device__ double chol_solve_lds(Ctx& c, const double* Lm, int n, double b) {
+// Solve A x = b for a symmetric positive definite A held in LDS (lower triangle, leading dim ld): lane i loads row i
+// into registers, the wave runs a right-looking LDL^T entirely with v_readlane broadcasts (no LDS traffic, no barriers;
+// fully unrolled so every register index is static), forward-substitutes, transposes L through LDS once (`T`, nv x ld)
+// and back-substitutes.  Lane i holds b_i on entry and returns x_i.  *fail is wave-uniform.
+template <class C>
+__device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* T, double b, int* fail) {
+  constexpr int NV = C::NV;
   const int lane = c.lane, ld = c.P->L.ld;
+  const int li = lane < NV ? lane : NV - 1;
+  double a[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) a[k] = A[li * ld + (k <= li ? k : li)];
+  double dinv = 0;
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    double ajj = readlane_f64(a[j], j);
+    if (ajj < MINVAL) bad = 1;
+    double r = fast_rcp(ajj);
+    double lij = a[j] * r;
+#pragma unroll
+    for (int k = j + 1; k < NV; k++) a[k] -= lij * readlane_f64(a[j], k);  // lanes < k only touch unused entries
+    if (lane == j) dinv = r;
+    a[j] = lij;
+  }
   double y = b;
-  double dinv = (lane < n) ? 1.0 / Lm[lane * ld + lane] : 0.0;
-  for (int k = 0; k < n; k++) {
-    double yk = __shfl(y, k, WAVE) * __shfl(dinv, k, WAVE);
-    if (lane == k) y = yk;
-    else if (lane > k && lane < n) y -= Lm[lane * ld + k] * yk;
+#pragma unroll
+  for (int k = 0; k < NV - 1; k++) {
+    double yk = readlane_f64(y, k);
+    if (lane > k) y -= a[k] * yk;
   }
-  for (int k = n - 1; k >= 0; k--) {
-    double xk = __shfl(y, k, WAVE) * __shfl(dinv, k, WAVE);
-    if (lane == k) y = xk;
-    else if (lane < k) y -= Lm[k * ld + lane] * xk;
+  y *= dinv;
+#pragma unroll
+  for (int k = 0; k < NV - 1; k++)
+    if (lane > k && lane < NV) T[k * ld + lane] = a[k];  // T[i][k] = L[k][i]
+  SYNC();
+  double t[NV];
+#pragma unroll
+  for (int k = 1; k < NV; k++) t[k] = T[li * ld + k];
+#pragma unroll
+  for (int k = NV - 1; k > 0; k--) {
+    double xk = readlane_f64(y, k);
+    if (lane < k) y -= t[k] * xk;
   }
+  SYNC();
+  *fail = bad;
   return y;
 }
 
 // cost(x) = 1/2 (Ma - qfrc_smooth).(x - qacc_smooth) + sum_active 1/2 D jar^2
-__device__ double solver_cost(Ctx& c, double Ma_i, double x_i) {
+template <class C>
+__device__ __forceinline__ double solver_cost(C& c, double Ma_i, double x_i) {
   const int lane = c.lane, nv = c.P->mdl.nv;
   double v = 0;
   if (lane < nv) v = 0.5 * (Ma_i - S(qsm)[lane]) * (x_i - S(asmo)[lane]);
@@ -854,7 +921,8 @@ __device__ double solver_cost(Ctx& c, double Ma_i, double x_i) {
   return wave_sum(v);
 }
 
-__device__ void newton_solve(Ctx& c) {
+template <class C>
+__device__ __forceinline__ void newton_solve(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const Aux& aux = c.P->aux;
   const int lane = c.lane, nv = mdl.nv, ld = c.P->L.ld, nefc = c.nefc, ncon = c.ncon, nlim = c.nlim;
@@ -895,6 +963,7 @@ __device__ void newton_solve(Ctx& c) {
     cost = solver_cost(c, Ma, xi);
   }
   int iters = 0;
+  PROF(11);
   for (int iter = 0; iter < maxiter; iter++) {
     iters++;
     // ---- per-contact force / weight summaries of the active set
@@ -942,29 +1011,37 @@ __device__ void newton_solve(Ctx& c) {
       S(dlim)[lane] = dl;
     }
     double gn = wave_sum(g * g);
+    PROF(12);
     if (scale * sqrt(gn) < tol) break;
     SYNC();
-    // ---- Hessian H = M + J^T diag(D_active) J, lower triangle, entry-major gather
-    for (int t = lane; t < aux.ntri; t += WAVE) {
-      int i = AI(tri_i)[t], jj = AI(tri_j)[t];
-      double h = S(M)[i * ld + jj];
-      if (i == jj) h += S(dlim)[i];
-      for (int ci = 0; ci < ncon; ci++) {
-        int si = slotof[ci * nv + i], sj = slotof[ci * nv + jj];
-        if (si != 0xFF && sj != 0xFF) {
-          const double* Jb = S(Jb) + 48 * ci;
-          const double* W = S(cW) + 6 * ci;
-          double a0 = Jb[si], a1 = Jb[16 + si], a2 = Jb[32 + si], b0 = Jb[sj], b1 = Jb[16 + sj], b2 = Jb[32 + sj];
-          h += a0 * (W[0] * b0 + W[1] * b1 + W[2] * b2) + a1 * (W[1] * b0 + W[3] * b1) + a2 * (W[2] * b0 + W[4] * b2);
+    // ---- Hessian H = M + J^T diag(D_active) J, lower triangle: entry-major gather (every lane a few entries)
+#pragma unroll
+    for (int m = 0; m < C::EPL; m++) {
+      unsigned e = c.ent[m];
+      if (e != 0xFFFFu) {
+        int i = e >> 8, jj = e & 0xFF;
+        double h = S(M)[i * ld + jj];
+        if (i == jj) h += S(dlim)[i];
+        for (int ci = 0; ci < ncon; ci++) {
+          int si = slotof[ci * nv + i], sj = slotof[ci * nv + jj];
+          if (si != 0xFF && sj != 0xFF) {
+            const double* Jb = S(Jb) + 48 * ci;
+            const double* W = S(cW) + 6 * ci;
+            double a0 = Jb[si], a1 = Jb[16 + si], a2 = Jb[32 + si], b0 = Jb[sj], b1 = Jb[16 + sj], b2 = Jb[32 + sj];
+            h += a0 * (W[0] * b0 + W[1] * b1 + W[2] * b2) + a1 * (W[1] * b0 + W[3] * b1) + a2 * (W[2] * b0 + W[4] * b2);
+          }
         }
+        S(H)[i * ld + jj] = h;
       }
-      S(H)[i * ld + jj] = h;
     }
     SYNC();
-    if (cholesky_lds(c, S(H), nv)) break;
-    double sr = -chol_solve_lds(c, S(H), nv, lane < nv ? S(grad)[lane] : 0.0);
+    PROF(13);
+    int hfail;
+    double sr = -ldl_solve_rows(c, S(H), S(H), lane < nv ? S(grad)[lane] : 0.0, &hfail);
+    if (hfail) break;
     if (lane < nv) S(search)[lane] = sr;
     SYNC();
+    PROF(14);
     // ---- exact line search
     double Mv = dense_Mx(c, S(search));
     contact_Jx(c, S(search));
@@ -988,6 +1065,7 @@ __device__ void newton_solve(Ctx& c) {
       if (an <= lo || (hi >= 0 && an >= hi)) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * (alpha > 0 ? alpha : 1.0);
       alpha = an;
     }
+    PROF(15);
     if (alpha == 0) break;
     if (lane < nv) { xi += alpha * sr; x[lane] = xi; Ma += alpha * Mv; }
     for (int r = lane; r < nefc; r += WAVE) S(jar)[r] += alpha * S(Jv)[r];
@@ -1002,7 +1080,8 @@ __device__ void newton_solve(Ctx& c) {
 }
 
 // ---- mj_forward ----------------------------------------------------------------------------------------------
-__device__ void forward(Ctx& c) {
+template <class C>
+__device__ __forceinline__ void forward(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane, nv = mdl.nv;
   c.st_forward++;
@@ -1013,7 +1092,9 @@ __device__ void forward(Ctx& c) {
   contact_Jx(c, S(qvel));
   for (int r = lane; r < c.nefc; r += WAVE) S(aref)[r] = -S(Jv)[r] * row_Jx(c, r, S(qvel)) - S(jar)[r];
   SYNC();
+  PROF(8);
   mass_matrix(c);  // last user of the kinematic scratch; H may overwrite it from here on
+  PROF(9);
   // smooth forces: passive (damping) - bias + actuation
   if (lane < nv) S(qsm)[lane] = -MF(dof_damping)[lane] * S(qvel)[lane] - S(bias)[lane];
   SYNC();
@@ -1025,13 +1106,14 @@ __device__ void forward(Ctx& c) {
   }
   SYNC();
   // qacc_smooth = M^-1 qfrc_smooth
-  for (int i = lane; i < nv * c.P->L.ld; i += WAVE) S(H)[i] = S(M)[i];
-  SYNC();
-  int fail = cholesky_lds(c, S(H), nv);
-  double as = fail ? 0.0 : chol_solve_lds(c, S(H), nv, lane < nv ? S(qsm)[lane] : 0.0);
+  int mfail;
+  double as = ldl_solve_rows(c, S(M), S(H), lane < nv ? S(qsm)[lane] : 0.0, &mfail);
+  if (mfail) as = 0.0;
   if (lane < nv) S(asmo)[lane] = as;
   SYNC();
+  PROF(10);
   newton_solve(c);
+  PROF(16);
   c.st_ncon += c.ncon;
   c.st_nefc += c.nefc;
   if (c.ncon > c.st_maxcon) c.st_maxcon = c.ncon;
@@ -1040,7 +1122,8 @@ __device__ void forward(Ctx& c) {
 }
 
 // qpos '+'= h * vel  (vel in LDS), one lane per joint
-__device__ void integrate_pos(Ctx& c, double* qpos, const double* vel, double h) {
+template <class C>
+__device__ __forceinline__ void integrate_pos(C& c, double* qpos, const double* vel, double h) {
   const sumo_model_t& mdl = c.P->mdl;
   int j = c.lane;
   if (j < mdl.njnt) {
@@ -1059,37 +1142,46 @@ __device__ void integrate_pos(Ctx& c, double* qpos, const double* vel, double h)
   }
 }
 
-__device__ void mj_step(Ctx& c) {
+// frame_skip x mj_step with the RK4 stages flattened into one loop, so forward() has a single (inlined) call site.
+// RK4 tableau (MuJoCo): A = diag(1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6); the warm start saved at the end of a step is
+// the last stage's qacc.
+template <class C>
+__device__ __forceinline__ void mj_steps(C& c, int nsteps) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane, nq = mdl.nq, nv = mdl.nv;
   const double h = MF(opt)[SUMO_OPT_TIMESTEP];
-  forward(c);
-  if (lane < nq) S(x0)[lane] = S(qpos)[lane];
-  if (lane < nv) {
-    S(x0)[nq + lane] = S(qvel)[lane];
-    S(accv)[lane] = 0.0 + (1.0 / 6.0) * S(qvel)[lane];
-    S(acca)[lane] = 0.0 + (1.0 / 6.0) * S(x)[lane];
-  }
-  SYNC();
-  for (int i = 1; i < 4; i++) {
-    // RK4 tableau: A = diag(1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
-    const double Ai = i == 3 ? 1.0 : 0.5, Bi = i == 3 ? 1.0 / 6.0 : 1.0 / 3.0;
-    double dv = 0;
-    if (lane < nv) { S(tmpv)[lane] = Ai * S(qvel)[lane]; dv = Ai * S(x)[lane]; }
-    if (lane < nq) S(qpos)[lane] = S(x0)[lane];
-    SYNC();
-    integrate_pos(c, S(qpos), S(tmpv), h);
-    if (lane < nv) S(qvel)[lane] = S(x0)[nq + lane] + h * dv;
-    SYNC();
+  for (int sub = 0; sub < 4 * nsteps; sub++) {
+    const int stage = sub & 3;
     forward(c);
-    if (lane < nv) { S(accv)[lane] += Bi * S(qvel)[lane]; S(acca)[lane] += Bi * S(x)[lane]; }
+    if (stage == 0) {
+      if (lane < nq) S(x0)[lane] = S(qpos)[lane];
+      if (lane < nv) {
+        S(x0)[nq + lane] = S(qvel)[lane];
+        S(accv)[lane] = 0.0 + (1.0 / 6.0) * S(qvel)[lane];
+        S(acca)[lane] = 0.0 + (1.0 / 6.0) * S(x)[lane];
+      }
+    } else {
+      const double Bi = stage == 3 ? 1.0 / 6.0 : 1.0 / 3.0;
+      if (lane < nv) { S(accv)[lane] += Bi * S(qvel)[lane]; S(acca)[lane] += Bi * S(x)[lane]; }
+    }
     SYNC();
+    if (stage < 3) {
+      const double Ai = stage == 2 ? 1.0 : 0.5;  // A[stage]
+      double dv = 0;
+      if (lane < nv) { S(tmpv)[lane] = Ai * S(qvel)[lane]; dv = Ai * S(x)[lane]; }
+      if (lane < nq) S(qpos)[lane] = S(x0)[lane];
+      SYNC();
+      integrate_pos(c, S(qpos), S(tmpv), h);
+      if (lane < nv) S(qvel)[lane] = S(x0)[nq + lane] + h * dv;
+      SYNC();
+    } else {
+      if (lane < nq) S(qpos)[lane] = S(x0)[lane];
+      if (lane < nv) { S(qvel)[lane] = S(x0)[nq + lane] + h * S(acca)[lane]; S(warm)[lane] = S(x)[lane]; }
+      SYNC();
+      integrate_pos(c, S(qpos), S(accv), h);
+      SYNC();
+    }
   }
-  if (lane < nq) S(qpos)[lane] = S(x0)[lane];
-  if (lane < nv) { S(qvel)[lane] = S(x0)[nq + lane] + h * S(acca)[lane]; S(warm)[lane] = S(x)[lane]; }
-  SYNC();
-  integrate_pos(c, S(qpos), S(accv), h);
-  SYNC();
 }
 
 // ---- RNG / reset / observation -----------------------------------------------------------------------------------
@@ -1110,7 +1202,8 @@ __device__ __forceinline__ double rng_uniform(uint64_t seed, uint32_t reset_coun
 }
 
 // sumo.py:232-253 with a counter RNG; state ends up in LDS (qpos, qvel, warm)
-__device__ void reset_state(Ctx& c, uint64_t seed, uint32_t rc) {
+template <class C>
+__device__ __forceinline__ void reset_state(C& c, uint64_t seed, uint32_t rc) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane, nq = mdl.nq, nv = mdl.nv;
   if (lane < nq) S(qpos)[lane] = MF(qpos0)[lane];
@@ -1144,7 +1237,8 @@ __device__ void reset_state(Ctx& c, uint64_t seed, uint32_t rc) {
 }
 
 // agents.py:190-214 (cfrc_ext == 0) + time feature (sumo_env.py:68-70)
-__device__ void write_obs(Ctx& c, float* obs, int obs_stride, int num_steps) {
+template <class C>
+__device__ __forceinline__ void write_obs(C& c, float* obs, int obs_stride, int num_steps) {
   const sumo_model_t& mdl = c.P->mdl;
   for (int idx = c.lane; idx < 2 * obs_stride; idx += WAVE) {
     int a = idx >= obs_stride, k = idx - a * obs_stride, o = 1 - a;
@@ -1161,7 +1255,7 @@ __device__ void write_obs(Ctx& c, float* obs, int obs_stride, int num_steps) {
   }
 }
 
-__device__ float sumsq_f32(const float* a, int n) {  // numpy float32 pairwise sum of squares (n < 128)
+__device__ __forceinline__ float sumsq_f32(const float* a, int n) {  // numpy float32 pairwise sum of squares (n < 128)
   if (n < 8) { float r = 0.0f; for (int i = 0; i < n; i++) r += a[i] * a[i]; return r; }
   float r[8];
   for (int j = 0; j < 8; j++) r[j] = a[j] * a[j];
@@ -1173,16 +1267,27 @@ __device__ float sumsq_f32(const float* a, int n) {  // numpy float32 pairwise s
   return res;
 }
 
-__device__ void ctx_init(Ctx& c, const Params* P, double* smem) {
+template <class C>
+__device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.P = P;
   c.sm = smem;
   c.si = (int*)(smem + P->L.i_base);
   c.sb = (unsigned char*)(smem + P->L.i_base);
   c.lane = threadIdx.x;
+#pragma unroll
+  for (int m = 0; m < C::EPL; m++) {
+    int t = c.lane + WAVE * m;
+    c.ent[m] = t < P->aux.ntri ? (unsigned)((P->aux.ai[P->aux.o_tri_i + t] << 8) | P->aux.ai[P->aux.o_tri_j + t]) : 0xFFFFu;
+  }
   c.ncon = c.nlim = c.nefc = c.ndropped = 0;
   c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = 0;
+#ifdef SUMO_PROFILE
+  for (int k = 0; k < 20; k++) c.prof[k] = 0;
+  c.tprev = clock64();
+#endif
 }
-__device__ void load_state(Ctx& c, const StepArgs& a, int e) {
+template <class C>
+__device__ __forceinline__ void load_state(C& c, const StepArgs& a, int e) {
   const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
   const double* st = a.state + (size_t)e * a.state_stride;
   for (int i = lane; i < nq + 2 * nv; i += WAVE) {
@@ -1190,13 +1295,15 @@ __device__ void load_state(Ctx& c, const StepArgs& a, int e) {
     if (i < nq) S(qpos)[i] = v; else if (i < nq + nv) S(qvel)[i - nq] = v; else S(warm)[i - nq - nv] = v;
   }
 }
-__device__ void store_state(Ctx& c, const StepArgs& a, int e) {
+template <class C>
+__device__ __forceinline__ void store_state(C& c, const StepArgs& a, int e) {
   const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
   double* st = a.state + (size_t)e * a.state_stride;
   for (int i = lane; i < nq + 2 * nv; i += WAVE)
     st[i] = i < nq ? S(qpos)[i] : (i < nq + nv ? S(qvel)[i - nq] : S(warm)[i - nq - nv]);
 }
-__device__ void flush_stats(Ctx& c, unsigned long long* stats) {
+template <class C>
+__device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
   if (c.lane == 0 && stats) {
     atomicAdd(stats + 0, (unsigned long long)c.st_forward);
     atomicAdd(stats + 1, (unsigned long long)c.st_newton);
@@ -1206,6 +1313,9 @@ __device__ void flush_stats(Ctx& c, unsigned long long* stats) {
     atomicMax(stats + 5, (unsigned long long)c.st_maxefc);
     atomicMax(stats + 6, (unsigned long long)c.st_maxnewton);
     atomicAdd(stats + 7, (unsigned long long)c.st_dropped);
+#ifdef SUMO_PROFILE
+    for (int k = 0; k < 20; k++) atomicAdd(stats + 8 + k, c.prof[k]);
+#endif
   }
 }
 
@@ -1214,8 +1324,9 @@ __device__ void flush_stats(Ctx& c, unsigned long long* stats) {
 // ---------------------------------------------------------------------------------------------------------
 extern __shared__ double smem_dyn[];
 
+template <int NV>
 __global__ void __launch_bounds__(WAVE) sumo_step_kernel(const Params* P, StepArgs a) {
-  Ctx c;
+  Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
   const int e = blockIdx.x, lane = c.lane;
@@ -1234,7 +1345,9 @@ __global__ void __launch_bounds__(WAVE) sumo_step_kernel(const Params* P, StepAr
   double before[2][2];
   for (int g = 0; g < 2; g++) { int qa = MI(agent_qposadr)[g]; before[g][0] = S(qpos)[qa]; before[g][1] = S(qpos)[qa + 1]; }
   SYNC();
-  for (int f = 0; f < mdl.frame_skip; f++) mj_step(c);
+  PROF(17);
+  mj_steps(c, mdl.frame_skip);
+  PROF(18);
   // ---- game rules (sumo.py:120-202), evaluated redundantly by every lane (wave-uniform result)
   double after[2][2], z[2];
   for (int g = 0; g < 2; g++) {
@@ -1291,11 +1404,13 @@ __global__ void __launch_bounds__(WAVE) sumo_step_kernel(const Params* P, StepAr
   write_obs(c, a.obs + (size_t)e * 2 * a.obs_stride, a.obs_stride, num_steps);
   store_state(c, a, e);
   if (lane == 0) { cnt[0] = num_steps; cnt[1] = reset_count; st[mdl.nq + 2 * mdl.nv] = ep_ret; st[mdl.nq + 2 * mdl.nv + 1] = ep_dense; }
+  PROF(19);
   flush_stats(c, a.stats);
 }
 
+template <int NV>
 __global__ void __launch_bounds__(WAVE) sumo_reset_kernel(const Params* P, StepArgs a) {
-  Ctx c;
+  Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
   const int e = blockIdx.x, lane = c.lane;
@@ -1313,8 +1428,9 @@ __global__ void __launch_bounds__(WAVE) sumo_reset_kernel(const Params* P, StepA
   }
 }
 
+template <int NV>
 __global__ void __launch_bounds__(WAVE) sumo_forward_kernel(const Params* P, StepArgs a) {
-  Ctx c;
+  Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
   const int e = blockIdx.x, lane = c.lane;
@@ -1333,6 +1449,7 @@ __global__ void __launch_bounds__(WAVE) sumo_forward_kernel(const Params* P, Ste
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+#define SUMO_FOR_NV(X) X(28) X(32) X(36) X(40) X(44)
 static thread_local char g_err[512];
 extern "C" const char* sumo_last_error(void) { return g_err; }
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return code; } while (0)
@@ -1369,6 +1486,7 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
   int nb = m->nbody, nv = m->nv;
   if (nb > WAVE || nv > WAVE || m->njnt > WAVE || m->nq > WAVE) FAIL(-10, "scene too large for one wavefront per env (nbody %d nv %d)", nb, nv);
   if (m->nagent != 2) FAIL(-11, "exactly two agents expected");
+  if (nv != 28 && nv != 32 && nv != 36 && nv != 40 && nv != 44) FAIL(-18, "no kernel variant for nv=%d", nv);
   const int* parent = SUMO_I(m, body_parentid);
   std::vector<int> depth(nb, 0);
   int ndepth = 1;
@@ -1454,7 +1572,7 @@ static void build_layout(sumo_engine* E) {
   L.H = kin0;
   if (kin1 - kin0 < nv * L.ld) o = kin0 + nv * L.ld;
   L.M = take(nv * L.ld); L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = take(nv); L.grad = take(nv);
-  L.search = take(nv); L.Mv = take(nv); L.x = take(nv); L.dlim = take(nv);
+  L.search = take(nv); L.Mv = take(nv); L.x = take(nv); L.dlim = take(nv); L.col = take(2 * WAVE); L.dinv = take(WAVE);
   L.cond = take(14 * L.maxcon); L.Jb = take(48 * L.maxcon); L.cpar = take(4 * L.maxcon); L.cW = take(6 * L.maxcon);
   L.cp = take(3 * L.maxcon);
   L.jar = take(L.maxefc); L.Jv = take(L.maxefc); L.D = take(L.maxefc); L.aref = take(L.maxefc);
@@ -1527,8 +1645,8 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
   std::vector<uint64_t> seeds(N);
   for (size_t i = 0; i < N; i++) seeds[i] = i;
   HIPCHK(hipMemcpy(E->d_seeds, seeds.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc((void**)&E->d_stats, 8 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(E->d_stats, 0, 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc((void**)&E->d_stats, 32 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(E->d_stats, 0, 32 * sizeof(unsigned long long)));
   // qpos = qpos0 for every env until the first reset / set_state
   {
     std::vector<double> st(N * E->state_stride, 0.0);
@@ -1536,9 +1654,14 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
     HIPCHK(hipMemcpy(E->d_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (E->L.total_bytes > 64 * 1024) {
-    HIPCHK(hipFuncSetAttribute((const void*)sumo_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E->L.total_bytes));
-    HIPCHK(hipFuncSetAttribute((const void*)sumo_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E->L.total_bytes));
-    HIPCHK(hipFuncSetAttribute((const void*)sumo_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E->L.total_bytes));
+#define X(NVV)                                                                                                         \
+    if (E->hm.nv == NVV) {                                                                                            \
+      HIPCHK(hipFuncSetAttribute((const void*)sumo_step_kernel<NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, E->L.total_bytes));    \
+      HIPCHK(hipFuncSetAttribute((const void*)sumo_reset_kernel<NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, E->L.total_bytes));   \
+      HIPCHK(hipFuncSetAttribute((const void*)sumo_forward_kernel<NVV>, hipFuncAttributeMaxDynamicSharedMemorySize, E->L.total_bytes)); \
+    }
+    SUMO_FOR_NV(X)
+#undef X
   }
   *out = E;
   return 0;
@@ -1546,9 +1669,9 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
 
 extern "C" int sumo_destroy(sumo_handle_t E) {
   if (!E) return 0;
-  hipSetDevice(E->device);
-  hipFree(E->d_params); hipFree(E->d_blob); hipFree(E->d_ai); hipFree(E->d_af); hipFree(E->d_pic); hipFree(E->d_state);
-  hipFree(E->d_counters); hipFree(E->d_seeds); hipFree(E->d_stats);
+  (void)hipSetDevice(E->device);
+  (void)hipFree(E->d_params); (void)hipFree(E->d_blob); (void)hipFree(E->d_ai); (void)hipFree(E->d_af); (void)hipFree(E->d_pic); (void)hipFree(E->d_state);
+  (void)hipFree(E->d_counters); (void)hipFree(E->d_seeds); (void)hipFree(E->d_stats);
   delete E;
   return 0;
 }
@@ -1561,6 +1684,22 @@ extern "C" int sumo_dims(sumo_handle_t E, int32_t* o) {
   memcpy(o, v, sizeof v);
   return 0;
 }
+
+// kernel variants by nv (the factorisation is unrolled over a compile-time nv); the nine registered scenes have
+// nv in {28, 32, 36, 40, 44}
+#define SUMO_DISPATCH(KERNEL, E, stream, args)                                                              \
+  do {                                                                                                       \
+    dim3 g_((E)->N), b_(WAVE);                                                                               \
+    size_t lds_ = (size_t)(E)->L.total_bytes;                                                                \
+    switch ((E)->hm.nv) {                                                                                    \
+      case 28: hipLaunchKernelGGL(KERNEL<28>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
+      case 32: hipLaunchKernelGGL(KERNEL<32>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
+      case 36: hipLaunchKernelGGL(KERNEL<36>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
+      case 40: hipLaunchKernelGGL(KERNEL<40>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
+      case 44: hipLaunchKernelGGL(KERNEL<44>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
+      default: FAIL(-19, "no kernel variant for nv=%d", (E)->hm.nv);                                        \
+    }                                                                                                        \
+  } while (0)
 
 static StepArgs base_args(sumo_engine* E) {
   StepArgs a;
@@ -1580,7 +1719,7 @@ extern "C" int sumo_reset(sumo_handle_t E, const uint64_t* seeds_host, const uin
   }
   StepArgs a = base_args(E);
   a.mask = mask_dev; a.obs = obs_dev;
-  hipLaunchKernelGGL(sumo_reset_kernel, dim3(E->N), dim3(WAVE), E->L.total_bytes, s, E->d_params, a);
+  SUMO_DISPATCH(sumo_reset_kernel, E, s, a);
   HIPCHK(hipGetLastError());
   if (seeds_host) HIPCHK(hipStreamSynchronize(s));  // seeds_host may be freed by the caller after return
   return 0;
@@ -1593,7 +1732,7 @@ extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_d
   StepArgs a = base_args(E);
   a.actions = actions_dev; a.obs = obs_dev; a.info = info_dev; a.done = done_dev; a.ep_r = ep_r_dev; a.ep_dr = ep_dr_dev;
   a.ep_l = ep_l_dev;
-  hipLaunchKernelGGL(sumo_step_kernel, dim3(E->N), dim3(WAVE), E->L.total_bytes, (hipStream_t)stream, E->d_params, a);
+  SUMO_DISPATCH(sumo_step_kernel, E, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1653,12 +1792,22 @@ extern "C" int sumo_debug_forward(sumo_handle_t E, const double* ctrl, double* q
   HIPCHK(hipMemcpy(d_ctrl, ctrl, N * m->nu * sizeof(double), hipMemcpyHostToDevice));
   StepArgs a = base_args(E);
   a.stats = nullptr; a.dbg_ctrl = d_ctrl; a.dbg_qacc = d_qacc; a.dbg_counts = d_cnt;
-  hipLaunchKernelGGL(sumo_forward_kernel, dim3(E->N), dim3(WAVE), E->L.total_bytes, 0, E->d_params, a);
+  SUMO_DISPATCH(sumo_forward_kernel, E, (hipStream_t)0, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(qacc, d_qacc, N * m->nv * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(counts, d_cnt, N * 4 * sizeof(int), hipMemcpyDeviceToHost));
-  hipFree(d_ctrl); hipFree(d_qacc); hipFree(d_cnt);
+  (void)hipFree(d_ctrl); (void)hipFree(d_qacc); (void)hipFree(d_cnt);
+  return 0;
+}
+
+extern "C" int sumo_profile(sumo_handle_t E, double* out20) {  // cycle totals per phase (SUMO_PROFILE builds only)
+  if (!E || !out20) FAIL(-1, "bad arguments");
+  HIPCHK(hipSetDevice(E->device));
+  HIPCHK(hipDeviceSynchronize());
+  unsigned long long h[32];
+  HIPCHK(hipMemcpy(h, E->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 20; i++) out20[i] = (double)h[8 + i];
   return 0;
 }
 
