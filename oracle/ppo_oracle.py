@@ -1,0 +1,287 @@
+"""numpy restatement of the PPO2 self-play rollout / update arithmetic.  TEST INFRASTRUCTURE ONLY (see oracle/README).
+
+Pinned (tests/test_ppo_oracle.py) against golden vectors produced by the reference's own Runner
+(tests/golden/runner_*.npz, generator tests/golden/make_runner_golden.py).  The TensorFlow parts of the reference
+(policies.py, model.py, baselines distributions / Adam) cannot be imported here (no tensorflow): those functions are
+restated from the cited lines and checked with finite differences / known answers -- parity unpinned for them.
+
+Each function cites the reference lines it follows.
+"""
+import numpy as np
+
+LOG2PI = np.log(2.0 * np.pi)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# rollout: reference runner.py:27-260
+# ----------------------------------------------------------------------------------------------------------
+def sf01(arr):
+    """runner.py:255-260"""
+    s = arr.shape
+    return arr.swapaxes(1, 2).reshape(s[0], s[1] * s[2], *s[3:])
+
+
+def sf0(arr):
+    """runner.py:263-267"""
+    return arr.swapaxes(0, 1).ravel()
+
+
+def anneal_alpha(update, anneal_bound):
+    """runner.py:128-130"""
+    if update <= anneal_bound:
+        return np.linspace(1, 0, anneal_bound)[update - 1]
+    return 0
+
+
+def vtrace_returns(rewards, values, dones, last_dones, last_values, rho_clip, c_clip, gamma):
+    """runner.py:174-196 for one agent.  rewards/values float32 [T,N]; dones bool [T,N] (done flags BEFORE each step);
+    last_dones bool [N]; last_values float32 [N]; rho_clip, c_clip float32 [T,N] (c already multiplied by lam).
+    Mixed precision exactly as numpy evaluates the reference expression: gamma*nextvalues in float32, the rest in
+    float64, result stored to float32."""
+    T = rewards.shape[0]
+    returns = np.zeros_like(rewards)
+    acc = np.zeros(rewards.shape[1])
+    g32 = np.float32(gamma)
+    for t in reversed(range(T)):
+        if t == T - 1:
+            nnt = 1.0 - last_dones
+            nextvalues = last_values
+        else:
+            nnt = 1.0 - dones[t + 1]
+            nextvalues = values[t + 1]
+        delta = rho_clip[t] * (rewards[t] + (g32 * nextvalues) * nnt - values[t])
+        acc = delta + gamma * nnt * c_clip[t] * acc
+        returns[t] = values[t] + acc
+    return returns
+
+
+class RunnerOracle:
+    """Same constructor / run() contract as the reference Runner (runner.py:7-252)."""
+
+    def __init__(self, *, env, models, nsteps, nagent, gamma, lam, rho_bar, c_bar, anneal_bound=500):
+        self.env, self.models, self.nsteps, self.nagent = env, models, nsteps, nagent
+        self.gamma, self.lam, self.rho_bar, self.c_bar, self.anneal_bound = gamma, lam, rho_bar, c_bar, anneal_bound
+        self.nenv = env.num_envs
+        self.obs = np.zeros((self.nenv, len(env.observation_space)) + env.observation_space[0].shape, np.float32)
+        self.obs[:] = env.reset()
+        self.dones = np.zeros((self.nenv, nagent), bool)
+
+    def run(self, update):
+        T, N, A = self.nsteps, self.nenv, self.nagent
+        mb_obs = [[] for _ in range(A)]
+        mb_rewards = [[] for _ in range(A)]
+        mb_actions = [[] for _ in range(A)]
+        mb_values = [[] for _ in range(A)]
+        mb_dones = [[] for _ in range(A)]
+        mb_nlp = [[] for _ in range(A)]
+        mb_onlp = [[] for _ in range(A)]
+        opp_obs, opp_act, epinfos = [], [], []
+        for _ in range(T):
+            acts = []
+            for agt in range(A):
+                o = self.obs[:, agt, :]
+                a, v, _, nlp = self.models[agt].step(o, S=None, M=self.dones[:, agt])
+                mb_obs[agt].append(o.copy())
+                mb_actions[agt].append(a)
+                mb_dones[agt].append(self.dones[:, agt])
+                if agt == 0:                                            # runner.py:82-85
+                    mb_values[0].append(v)
+                    mb_nlp[0].append(nlp)
+                    mb_onlp[0].append(self.models[1].act_model.action_probability(o, given_action=a))
+                else:                                                   # runner.py:86-96
+                    mb_onlp[agt].append(nlp)
+                    mb_values[agt].append(self.models[0].value(o, S=None, M=self.dones[:, agt]))
+                    mb_nlp[agt].append(self.models[0].act_model.action_probability(o, given_action=a))
+                    opp_obs.append(self.obs[:, 1, :].copy())
+                    opp_act.append(a)
+                acts.append(a)
+            self.obs[:], rewards, self.dones, infos = self.env.step(np.stack(acts, axis=1))
+            if "shaping_reward" in infos[0][0]:                         # runner.py:127-143
+                alpha = anneal_alpha(update, self.anneal_bound)
+                for agt in range(A):
+                    r = np.zeros(N)
+                    for e in range(N):
+                        r[e] = alpha * infos[e][agt]["shaping_reward"] + (1 - alpha) * infos[e][agt]["main_reward"]
+                        if agt == 0 and infos[e][0].get("episode"):
+                            epinfos.append(infos[e][0]["episode"])
+                    mb_rewards[agt].append(r)
+            else:                                                       # runner.py:144-151
+                for agt in range(A):
+                    mb_rewards[agt].append(rewards[:, agt])
+                    if agt == 0:
+                        for e in range(N):
+                            if infos[e][0].get("episode"):
+                                epinfos.append(infos[e][0]["episode"])
+        mb_obs = np.asarray(mb_obs, np.float32)
+        mb_rewards = np.asarray(mb_rewards, np.float32)
+        mb_actions = np.asarray(mb_actions)
+        mb_values = np.asarray(mb_values, np.float32)
+        mb_nlp = np.asarray(mb_nlp, np.float32)
+        mb_dones = np.asarray(mb_dones, bool)
+        mb_onlp = np.asarray(mb_onlp)
+        opp_obs = np.asarray(opp_obs, np.float32)
+        opp_act = np.asarray(opp_act)
+        off_policy = np.exp(mb_onlp[1] - mb_nlp[1])                     # runner.py:170-172
+        off_env = np.exp(mb_nlp[0] - mb_onlp[0])
+        ratio = off_policy * off_env
+        mb_returns = np.zeros_like(mb_rewards)
+        for agt in range(A):                                            # runner.py:174-196
+            if agt == 0:
+                rho, c = np.ones_like(ratio), np.ones_like(ratio)
+            else:
+                rho, c = np.clip(ratio, None, self.rho_bar), np.clip(ratio, None, self.c_bar)
+            c = c * np.float32(self.lam) if c.dtype == np.float32 else c * self.lam
+            last_values = self.models[0].value(self.obs[:, agt, :], S=None, M=self.dones[:, agt])
+            mb_returns[agt] = vtrace_returns(mb_rewards[agt], mb_values[agt], mb_dones[agt], self.dones[:, agt],
+                                             last_values, rho, c, self.gamma)
+        return (*map(sf01, (mb_obs, mb_returns, mb_dones, mb_actions, mb_values, mb_nlp, mb_rewards, mb_onlp, opp_obs,
+                            opp_act)), None, epinfos, *map(sf0, (off_policy, off_env, ratio)))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# policy / value network: policies.py:14-193, baselines common/models.py:74-103, a2c/utils.py:20-63,
+# common/distributions.py:96-113,227-251
+# ----------------------------------------------------------------------------------------------------------
+PARAM_NAMES = ["pi/mlp_fc0/w", "pi/mlp_fc0/b", "pi/mlp_fc1/w", "pi/mlp_fc1/b", "vf/mlp_fc0/w", "vf/mlp_fc0/b",
+               "vf/mlp_fc1/w", "vf/mlp_fc1/b", "pi/w", "pi/b", "pi/logstd", "vf/w", "vf/b"]
+
+
+def param_shapes(ob_dim, ac_dim, hidden=64):
+    return [(ob_dim, hidden), (hidden,), (hidden, hidden), (hidden,), (ob_dim, hidden), (hidden,), (hidden, hidden),
+            (hidden,), (hidden, ac_dim), (ac_dim,), (1, ac_dim), (hidden, 1), (1,)]
+
+
+def ortho_init(rng, shape, scale):
+    """a2c/utils.py:20-35 (numpy RNG + SVD)."""
+    a = rng.normal(0.0, 1.0, shape)
+    u, _, v = np.linalg.svd(a, full_matrices=False)
+    q = u if u.shape == shape else v
+    return (scale * q[:shape[0], :shape[1]]).astype(np.float32)
+
+
+def init_params(rng, ob_dim, ac_dim, hidden=64):
+    """Variable creation order and initialisers of policies.py:156-190,50,70 with value_network='copy'."""
+    p = []
+    for _ in range(2):                                    # pi then vf trunk
+        p += [ortho_init(rng, (ob_dim, hidden), np.sqrt(2)), np.zeros(hidden, np.float32),
+              ortho_init(rng, (hidden, hidden), np.sqrt(2)), np.zeros(hidden, np.float32)]
+    p += [ortho_init(rng, (hidden, ac_dim), 0.01), np.zeros(ac_dim, np.float32), np.zeros((1, ac_dim), np.float32),
+          ortho_init(rng, (hidden, 1), 1.0), np.zeros(1, np.float32)]
+    return p
+
+
+def forward(params, obs, dtype=np.float64):
+    """mean [n,A], value [n], plus the activations needed by backward()."""
+    p = [np.asarray(x, dtype) for x in params]
+    x = np.asarray(obs, dtype)
+    h1 = np.maximum(x @ p[0] + p[1], 0)
+    h2 = np.maximum(h1 @ p[2] + p[3], 0)
+    g1 = np.maximum(x @ p[4] + p[5], 0)
+    g2 = np.maximum(g1 @ p[6] + p[7], 0)
+    mean = h2 @ p[8] + p[9]
+    value = (g2 @ p[11] + p[12])[:, 0]
+    return mean, value, (x, h1, h2, g1, g2)
+
+
+def neglogp(mean, logstd, a):
+    """distributions.py:238-241"""
+    std = np.exp(logstd)
+    return 0.5 * np.sum(np.square((a - mean) / std), axis=-1) + 0.5 * LOG2PI * a.shape[-1] + np.sum(logstd, axis=-1)
+
+
+def entropy(logstd, n):
+    """distributions.py:245-246 (same for every row since logstd is state independent)"""
+    return np.full(n, np.sum(logstd + 0.5 * np.log(2.0 * np.pi * np.e)))
+
+
+def sample(mean, logstd, noise):
+    """distributions.py:247-248"""
+    return mean + np.exp(logstd) * noise
+
+
+# ----------------------------------------------------------------------------------------------------------
+# learner: model.py:22-213
+# ----------------------------------------------------------------------------------------------------------
+def normalize_advantages(returns, values):
+    """model.py:180-185 (float32 numpy, population std)"""
+    advs = returns - values
+    return (advs - advs.mean()) / (advs.std() + 1e-8)
+
+
+def ppo_loss_and_grads(params, obs, actions, advs, returns, oldneglogp, is_weight, cliprange, ent_coef, vf_coef,
+                       dtype=np.float64):
+    """Loss of model.py:65-111 and its gradient w.r.t. the 13 parameter tensors (manual backprop).
+    Returns (loss, stats[5] = pg_loss, vf_loss, entropy, approxkl, clipfrac, log_ratio[n], grads list)."""
+    p = [np.asarray(x, dtype) for x in params]
+    A = np.asarray(actions, dtype)
+    adv, R, old, w = (np.asarray(v, dtype) for v in (advs, returns, oldneglogp, is_weight))
+    n = A.shape[0]
+    mean, value, (x, h1, h2, g1, g2) = forward(p, obs, dtype)
+    logstd = p[10]
+    std = np.exp(logstd)
+    nlp = neglogp(mean, logstd, A)
+    ent = np.sum(logstd + 0.5 * np.log(2.0 * np.pi * np.e))
+    vf_loss = 0.5 * np.mean(np.square(value - R))                       # model.py:82-89 (no value clipping)
+    log_ratio = old - nlp
+    ratio = np.exp(log_ratio)
+    nanmask = np.isnan(ratio)
+    ratio = np.where(nanmask, 2.0, ratio)                                # model.py:96
+    l1 = -adv * ratio
+    l2 = -adv * np.clip(ratio, 1.0 - cliprange, 1.0 + cliprange)
+    pg_loss = np.mean(w * np.maximum(l1, l2))                            # model.py:100-105
+    approxkl = np.mean(nlp - old)                                        # model.py:106
+    clipfrac = np.mean((np.abs(ratio - 1.0) > cliprange).astype(dtype))
+    loss = pg_loss - ent * ent_coef + vf_loss * vf_coef                  # model.py:111
+    # ---- backward
+    # d pg / d ratio: max picks l1 unless l2 > l1 (tf.maximum gradient goes to the first arg on ties)
+    in_clip = (ratio >= 1.0 - cliprange) & (ratio <= 1.0 + cliprange)
+    d_l1 = (l1 >= l2).astype(dtype)
+    d_l2 = 1.0 - d_l1
+    dratio = w / n * (d_l1 * (-adv) + d_l2 * (-adv) * in_clip)
+    dratio = np.where(nanmask, 0.0, dratio)
+    dnlp = dratio * ratio * (-1.0)                                       # ratio = exp(old - nlp)
+    z = (A - mean) / std
+    dmean = dnlp[:, None] * (-(z / std))                                 # d nlp / d mean = -(a-mean)/std^2
+    dlogstd = np.sum(dnlp[:, None] * (-(z * z) + 1.0), axis=0, keepdims=True) - ent_coef * np.ones_like(logstd)
+    dvalue = vf_coef * (value - R) / n
+    grads = [None] * 13
+    grads[8] = h2.T @ dmean
+    grads[9] = dmean.sum(0)
+    grads[10] = dlogstd
+    dh2 = (dmean @ p[8].T) * (h2 > 0)
+    grads[2] = h1.T @ dh2
+    grads[3] = dh2.sum(0)
+    dh1 = (dh2 @ p[2].T) * (h1 > 0)
+    grads[0] = x.T @ dh1
+    grads[1] = dh1.sum(0)
+    grads[11] = g2.T @ dvalue[:, None]
+    grads[12] = np.array([dvalue.sum()])
+    dg2 = (dvalue[:, None] @ p[11].T) * (g2 > 0)
+    grads[6] = g1.T @ dg2
+    grads[7] = dg2.sum(0)
+    dg1 = (dg2 @ p[6].T) * (g1 > 0)
+    grads[4] = x.T @ dg1
+    grads[5] = dg1.sum(0)
+    stats = np.array([pg_loss, vf_loss, ent, approxkl, clipfrac])
+    return loss, stats, log_ratio, grads
+
+
+def clip_by_global_norm(grads, max_norm):
+    """tf.clip_by_global_norm (model.py:130-132): g * clip / max(norm, clip)"""
+    norm = np.sqrt(sum(float(np.sum(np.square(g.astype(np.float64)))) for g in grads))
+    scale = max_norm / max(norm, max_norm)
+    return [g * scale for g in grads], norm
+
+
+def adam_step(params, grads, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-5):
+    """tf.train.AdamOptimizer (model.py:121; TF1 formulation, epsilon OUTSIDE the bias correction):
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m/(sqrt(v)+eps)."""
+    lr_t = lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    out_p, out_m, out_v = [], [], []
+    for p, g, mm, vv in zip(params, grads, m, v):
+        mm = beta1 * mm + (1 - beta1) * g
+        vv = beta2 * vv + (1 - beta2) * g * g
+        out_p.append(p - lr_t * mm / (np.sqrt(vv) + eps))
+        out_m.append(mm)
+        out_v.append(vv)
+    return out_p, out_m, out_v
