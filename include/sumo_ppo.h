@@ -1,0 +1,84 @@
+/* sumo_ppo.h -- C ABI of the MI355X-native PPO2 self-play arithmetic (libsumo_ppo.so).
+ *
+ * Stands in for the TF1 graph + numpy glue of the reference's learner/rollout path.  Each entry point names the
+ * reference code it replaces (paths relative to the reference checkout):
+ *
+ *   ppo_param_count / layout    PPOModel.save/load variable order (model.py:153-177):
+ *                               pi/mlp_fc0/{w,b} pi/mlp_fc1/{w,b} vf/mlp_fc0/{w,b} vf/mlp_fc1/{w,b} pi/{w,b,logstd} vf/{w,b}
+ *                               flattened row-major into ONE float32 vector, w stored [in][out] as TF does.
+ *   ppo_forward                 PolicyWithValue.step / .value / .action_probability (policies.py:84-128) over the
+ *                               mlp(64,64,relu) trunks (baselines/baselines/common/models.py:74-103) and the diagonal
+ *                               Gaussian head (baselines/baselines/common/distributions.py:96-113,227-251)
+ *   ppo_reward_mix              Runner.run reward curriculum (runner.py:127-143)
+ *   ppo_vtrace                  Runner.run IS ratios + V-trace targets (runner.py:166-196)
+ *   ppo_adv_moments/_normalize  PPOModel.train advantage normalisation (model.py:180-185); split in two so a
+ *                               multi-GPU run can all-reduce the three moments in between
+ *   ppo_grad                    loss + gradients of model.py:65-132 (sums, not means: divide by the global count)
+ *   ppo_clip_adam               tf.clip_by_global_norm + tf.train.AdamOptimizer(epsilon=1e-5).apply_gradients
+ *                               (model.py:121-139)
+ *
+ * All pointers are DEVICE pointers owned by the caller; `stream` is a hipStream_t as void*.  Return 0 / negative
+ * + ppo_last_error().  float32 arithmetic on MFMA (v_mfma_f32_16x16x4_f32, exact f32) for the dense layers.
+ */
+#ifndef SUMO_PPO_H
+#define SUMO_PPO_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPO_HIDDEN 64
+#define PPO_NSTATS 8 /* sum pg, sum vf, entropy, sum approxkl, sum clipfrac, sum w (unused), count, grad norm */
+
+const char* ppo_last_error(void);
+int ppo_param_count(int ob_dim, int ac_dim);
+
+/* flags for ppo_forward */
+#define PPO_FWD_PI 1        /* evaluate the policy trunk: mean / action / neglogp */
+#define PPO_FWD_VF 2        /* evaluate the value trunk: value */
+/* obs [n][obs_stride]; noise, given_action, action_out, mean_out [n][ac_dim] (any may be NULL);
+ * action = given_action if given, else mean + exp(logstd)*noise if noise given, else mean (deterministic);
+ * neglogp_out [n] = -log pi(action | obs); value_out [n]. */
+int ppo_forward(const float* params, const float* obs, int n, int obs_stride, int ob_dim, int ac_dim, int flags,
+                const float* noise, const float* given_action, float* action_out, float* neglogp_out,
+                float* value_out, float* mean_out, void* stream);
+
+/* info float64 [n][2][8] as written by sumo_step (slot 6 shaping, slot 3 main); reward_out float32 [2][n]
+ * (agent-major, one time slice of the rollout buffer) = alpha*shaping + (1-alpha)*main evaluated in float64. */
+int ppo_reward_mix(const double* info, int n, double alpha, float* reward_out, int agent_stride, void* stream);
+
+/* Buffers [2][T][N] float32 (agent, time, env); dones uint8 [2][T][N] = done flags BEFORE each step; last_dones uint8
+ * [N][2]; last_values float32 [2][N].  Outputs returns float32 [2][T][N], ratios float32 [T][N]. */
+int ppo_vtrace(const float* rewards, const float* values, const float* neglogp, const float* opp_neglogp,
+               const uint8_t* dones, const uint8_t* last_dones, const float* last_values, int T, int N, double gamma,
+               double lam, double rho_bar, double c_bar, float* returns, float* off_policy_ratio, float* off_env_ratio,
+               float* ratio, void* stream);
+
+/* minibatch rows are data rows idx[0..n) (idx may be NULL = identity).  moments double[3] = {sum adv, sum adv^2, n}
+ * with adv = returns - values. */
+int ppo_adv_moments(const float* returns, const float* values, const int32_t* idx, int n, double* moments, void* stream);
+int ppo_adv_normalize(const float* returns, const float* values, const int32_t* idx, int n, const double* moments,
+                      float* adv_out, void* stream);
+
+/* Gradient of the PPO loss over minibatch rows idx[0..n): grads float32 [P] receives d(sum-loss)/d(theta) with
+ * sum-loss = sum_i w_i*pg_i + vf_coef * sum_i 0.5 (v_i-R_i)^2 - n_local*ent_coef*entropy, where every per-row term
+ * is pre-divided by inv_count = 1/global_count (so summing grads over ranks gives the gradient of the global mean loss).
+ * stats double[PPO_NSTATS] accumulate the un-normalised sums.  log_ratio_out [n] (minibatch order) may be NULL.
+ * workspace: ppo_grad_workspace_bytes(ob_dim, ac_dim) bytes of scratch. */
+size_t ppo_grad_workspace_bytes(int ob_dim, int ac_dim);
+int ppo_grad(const float* params, const float* obs, int obs_stride, int ob_dim, int ac_dim, const float* actions,
+             const float* adv_mb, const float* returns, const float* old_neglogp, const float* is_weight,
+             const int32_t* idx, int n, double inv_count, float cliprange, float ent_coef, float vf_coef, float* grads,
+             double* stats, float* log_ratio_out, void* workspace, void* stream);
+
+/* params -= Adam(clip_by_global_norm(grads, max_grad_norm)); m, v float32 [P]; step t >= 1 (TF1 bias correction).
+ * max_grad_norm <= 0 disables clipping.  stats[7] receives the global gradient norm. */
+int ppo_clip_adam(float* params, const float* grads, float* m, float* v, int P, int t, double lr, double beta1,
+                  double beta2, double eps, double max_grad_norm, double* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,654 @@
+// ppo_kernels.hip -- MI355X (gfx950) kernels for the PPO2 self-play rollout / update arithmetic (include/sumo_ppo.h).
+//
+// Dense layers run on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact f32, so results stay comparable with
+// the reference's float32 TF graph).  One wavefront owns a 16-row tile of the batch: activations of the tile live in
+// LDS (row stride == 2 mod 32 floats -> conflict-free A-operand reads), weights are read straight from L2 as B
+// operands (24.5 k parameters, resident), weight gradients accumulate in MFMA accumulator registers across all tiles a
+// wave processes and are written once as a per-wave slab that a second kernel reduces in a fixed order (deterministic,
+// no float atomics).
+//
+// Reference arithmetic reproduced: policies.py:14-128 / baselines models.py:74-103 / distributions.py:227-251 (forward),
+// model.py:65-139 (loss, gradient clipping, Adam), model.py:180-185 (advantage normalisation), runner.py:127-143,166-196
+// (reward curriculum, IS ratios, V-trace).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sumo_ppo.h"
+
+#define WAVE 64
+#define H PPO_HIDDEN
+#define HS 66         /* LDS row stride of a 16 x 64 activation tile (== 2 mod 32) */
+#define MAXA 16       /* action dims are padded to one 16-column MFMA tile */
+#define LOG2PI_F 1.8378770664093453f
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+static thread_local char g_err[256];
+extern "C" const char* ppo_last_error(void) { return g_err; }
+#define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return code; } while (0)
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) FAIL(-100, "%s failed: %s", #expr, hipGetErrorString(_e)); } while (0)
+
+struct ParamLayout {  // offsets into the flat parameter vector (checkpoint order)
+  int D, A, P;
+  int pi_w0, pi_b0, pi_w1, pi_b1, vf_w0, vf_b0, vf_w1, vf_b1, pi_w, pi_b, logstd, vf_w, vf_b;
+};
+static ParamLayout make_layout(int D, int A) {
+  ParamLayout L;
+  L.D = D; L.A = A;
+  int o = 0;
+  L.pi_w0 = o; o += D * H; L.pi_b0 = o; o += H; L.pi_w1 = o; o += H * H; L.pi_b1 = o; o += H;
+  L.vf_w0 = o; o += D * H; L.vf_b0 = o; o += H; L.vf_w1 = o; o += H * H; L.vf_b1 = o; o += H;
+  L.pi_w = o; o += H * A; L.pi_b = o; o += A; L.logstd = o; o += A; L.vf_w = o; o += H; L.vf_b = o; o += 1;
+  L.P = o;
+  return L;
+}
+extern "C" int ppo_param_count(int ob_dim, int ac_dim) { return make_layout(ob_dim, ac_dim).P; }
+
+static int x_stride(int D) {  // LDS row stride of the staged observation tile: >= 16*ceil(D/16), == 2 mod 32
+  int cols = ((D + 15) / 16) * 16;
+  int s = cols;
+  while (s % 32 != 2) s++;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shared device pieces: one wave, one 16-row tile, one trunk
+// ---------------------------------------------------------------------------------------------------------
+struct Net { const float *w0, *b0, *w1, *b1, *w2, *b2; int nout; };
+
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+// stage 16 rows of obs (row ids from idx, or consecutive) into xbuf[16][XS], zero padded
+__device__ __forceinline__ void stage_x(float* xbuf, int XS, const float* obs, int obs_stride, int D, const int32_t* idx, int r0,
+                                        int n, int lane) {
+  for (int e = lane; e < 16 * XS; e += WAVE) {
+    int r = e / XS, c = e - r * XS;
+    float v = 0.0f;
+    int row = r0 + r;
+    if (row < n && c < D) {
+      int src = idx ? idx[row] : row;
+      v = obs[(size_t)src * obs_stride + c];
+    }
+    xbuf[e] = v;
+  }
+}
+
+// forward of one trunk on the staged tile.  h1buf/h2buf [16][HS] receive the relu activations; returns the head tile
+// (D layout: lane (i = lane&15, kq = lane>>4) holds rows 4kq+r, column i; columns >= nout are zero + garbage-free).
+__device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf, int XS, int D, float* h1buf, float* h2buf, int lane) {
+  const int i = lane & 15, kq = lane >> 4;
+  const int Dp = (D + 3) & ~3;
+  f32x4 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
+  for (int k0 = 0; k0 < Dp; k0 += 4) {
+    int k = k0 + kq;
+    float a = xbuf[i * XS + k];
+    bool ok = k < D;
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) {
+      float b = ok ? net.w0[k * H + ct * 16 + i] : 0.0f;
+      acc[ct] = MFMA(a, b, acc[ct]);
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) {
+    float bias = net.b0[ct * 16 + i];
+#pragma unroll
+    for (int r = 0; r < 4; r++) h1buf[(4 * kq + r) * HS + ct * 16 + i] = fmaxf(acc[ct][r] + bias, 0.0f);
+    acc[ct] = (f32x4){0, 0, 0, 0};
+  }
+  wave_sync();
+  for (int k0 = 0; k0 < H; k0 += 4) {
+    int k = k0 + kq;
+    float a = h1buf[i * HS + k];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a, net.w1[k * H + ct * 16 + i], acc[ct]);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) {
+    float bias = net.b1[ct * 16 + i];
+#pragma unroll
+    for (int r = 0; r < 4; r++) h2buf[(4 * kq + r) * HS + ct * 16 + i] = fmaxf(acc[ct][r] + bias, 0.0f);
+  }
+  wave_sync();
+  f32x4 out = (f32x4){0, 0, 0, 0};
+  const bool col_ok = i < net.nout;
+  for (int k0 = 0; k0 < H; k0 += 4) {
+    int k = k0 + kq;
+    float a = h2buf[i * HS + k];
+    float b = col_ok ? net.w2[k * net.nout + i] : 0.0f;
+    out = MFMA(a, b, out);
+  }
+  float bias = col_ok ? net.b2[i] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; r++) out[r] += bias;
+  return out;
+}
+
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes that share lane>>4
+  v += __shfl_xor(v, 1, WAVE); v += __shfl_xor(v, 2, WAVE); v += __shfl_xor(v, 4, WAVE); v += __shfl_xor(v, 8, WAVE);
+  return v;
+}
+__device__ __forceinline__ float kq_sum(float v) {  // sum over the 4 lanes that share lane&15
+  v += __shfl_xor(v, 16, WAVE); v += __shfl_xor(v, 32, WAVE);
+  return v;
+}
+
+__device__ __forceinline__ Net pi_net(const float* p, const ParamLayout& L) {
+  Net n = {p + L.pi_w0, p + L.pi_b0, p + L.pi_w1, p + L.pi_b1, p + L.pi_w, p + L.pi_b, L.A};
+  return n;
+}
+__device__ __forceinline__ Net vf_net(const float* p, const ParamLayout& L) {
+  Net n = {p + L.vf_w0, p + L.vf_b0, p + L.vf_w1, p + L.vf_b1, p + L.vf_w, p + L.vf_b, 1};
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// inference
+// ---------------------------------------------------------------------------------------------------------
+struct FwdArgs {
+  const float *params, *obs, *noise, *given;
+  float *action, *neglogp, *value, *mean;
+  int n, obs_stride, flags, XS;
+  ParamLayout L;
+};
+
+extern __shared__ float smem_f[];
+
+__global__ void __launch_bounds__(256) ppo_forward_kernel(FwdArgs a) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + wid, r0 = tile * 16;
+  if (r0 >= a.n) return;
+  const int XS = a.XS, D = a.L.D, A = a.L.A;
+  float* base = smem_f + wid * (16 * XS + 2 * 16 * HS);
+  float *xbuf = base, *h1 = base + 16 * XS, *h2 = h1 + 16 * HS;
+  const int i = lane & 15, kq = lane >> 4;
+  stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, lane);
+  wave_sync();
+  if (a.flags & PPO_FWD_PI) {
+    Net net = pi_net(a.params, a.L);
+    f32x4 mean = trunk_forward(net, xbuf, XS, D, h1, h2, lane);
+    const bool col = i < A;
+    float logstd = col ? a.params[a.L.logstd + i] : 0.0f;
+    float std = expf(logstd);
+    float sum_logstd = row16_sum(logstd);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int row = r0 + 4 * kq + r;
+      bool ok = col && row < a.n;
+      float m = mean[r], act = m;
+      if (ok) {
+        if (a.given) act = a.given[(size_t)row * A + i];
+        else if (a.noise) act = m + std * a.noise[(size_t)row * A + i];
+        if (a.action) a.action[(size_t)row * A + i] = act;
+        if (a.mean) a.mean[(size_t)row * A + i] = m;
+      }
+      float z = ok ? (act - m) / std : 0.0f;
+      float ss = row16_sum(z * z);
+      if (a.neglogp && i == 0 && row < a.n) a.neglogp[row] = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
+    }
+    wave_sync();
+  }
+  if (a.flags & PPO_FWD_VF) {
+    Net net = vf_net(a.params, a.L);
+    f32x4 v = trunk_forward(net, xbuf, XS, D, h1, h2, lane);
+    if (a.value && i == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { int row = r0 + 4 * kq + r; if (row < a.n) a.value[row] = v[r]; }
+    }
+  }
+}
+
+extern "C" int ppo_forward(const float* params, const float* obs, int n, int obs_stride, int ob_dim, int ac_dim, int flags,
+                           const float* noise, const float* given_action, float* action_out, float* neglogp_out,
+                           float* value_out, float* mean_out, void* stream) {
+  if (!params || !obs || n <= 0) FAIL(-1, "bad arguments");
+  if (ac_dim < 1 || ac_dim > MAXA) FAIL(-2, "ac_dim %d not in [1,%d]", ac_dim, MAXA);
+  if (ob_dim < 1 || ob_dim > 512 || obs_stride < ob_dim) FAIL(-3, "bad ob_dim/obs_stride");
+  FwdArgs a;
+  a.params = params; a.obs = obs; a.noise = noise; a.given = given_action; a.action = action_out; a.neglogp = neglogp_out;
+  a.value = value_out; a.mean = mean_out; a.n = n; a.obs_stride = obs_stride; a.flags = flags; a.XS = x_stride(ob_dim);
+  a.L = make_layout(ob_dim, ac_dim);
+  size_t lds = (size_t)4 * (16 * a.XS + 2 * 16 * HS) * sizeof(float);
+  int tiles = (n + 15) / 16;
+  if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ppo_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ppo_forward_kernel, dim3((tiles + 3) / 4), dim3(256), lds, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rollout arithmetic
+// ---------------------------------------------------------------------------------------------------------
+__global__ void ppo_reward_mix_kernel(const double* info, int n, double alpha, float* out, int agent_stride) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * n) return;
+  int e = t >> 1, g = t & 1;
+  const double* I = info + (size_t)(2 * e + g) * 8;
+  out[(size_t)g * agent_stride + e] = (float)(alpha * I[6] + (1 - alpha) * I[3]);  // runner.py:134
+}
+extern "C" int ppo_reward_mix(const double* info, int n, double alpha, float* reward_out, int agent_stride, void* stream) {
+  if (!info || !reward_out || n <= 0) FAIL(-1, "bad arguments");
+  hipLaunchKernelGGL(ppo_reward_mix_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, info, n, alpha, reward_out,
+                     agent_stride);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// one thread per env; reverse scan over T for both agents.  Mixed precision follows numpy's evaluation of
+// runner.py:186-190: gamma*nextvalues in float32, everything else promoted to float64, result stored as float32.
+__global__ void ppo_vtrace_kernel(const float* rew, const float* val, const float* nlp, const float* onlp, const uint8_t* dones,
+                                  const uint8_t* last_dones, const float* last_values, int T, int N, double gamma, float lam,
+                                  float rho_bar, float c_bar, float* ret, float* off_policy, float* off_env, float* ratio_out) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const size_t TN = (size_t)T * N;
+  const float g32 = (float)gamma;
+  double acc0 = 0, acc1 = 0;
+  for (int t = T - 1; t >= 0; t--) {
+    size_t o = (size_t)t * N + e;
+    float opr = expf(onlp[TN + o] - nlp[TN + o]);   // runner.py:170
+    float oer = expf(nlp[o] - onlp[o]);             // runner.py:171
+    float rt = opr * oer;
+    off_policy[o] = opr; off_env[o] = oer; ratio_out[o] = rt;
+    float rho1 = fminf(rt, rho_bar), c1 = fminf(rt, c_bar) * lam;
+    if (rt != rt) { rho1 = rt; c1 = rt; }           // np.clip propagates NaN
+    float c0 = 1.0f * lam;
+    for (int g = 0; g < 2; g++) {
+      double nnt;
+      float nextv;
+      if (t == T - 1) { nnt = 1.0 - (double)(last_dones[2 * e + g] != 0); nextv = last_values[(size_t)g * N + e]; }
+      else { nnt = 1.0 - (double)(dones[g * TN + o + N] != 0); nextv = val[g * TN + o + N]; }
+      float rho = g == 0 ? 1.0f : rho1, c = g == 0 ? c0 : c1;
+      double v = (double)val[g * TN + o];
+      double delta = (double)rho * (((double)rew[g * TN + o] + (double)(g32 * nextv) * nnt) - v);
+      double& acc = g == 0 ? acc0 : acc1;
+      acc = delta + ((gamma * nnt) * (double)c) * acc;
+      ret[g * TN + o] = (float)(v + acc);
+    }
+  }
+}
+extern "C" int ppo_vtrace(const float* rewards, const float* values, const float* neglogp, const float* opp_neglogp,
+                          const uint8_t* dones, const uint8_t* last_dones, const float* last_values, int T, int N, double gamma,
+                          double lam, double rho_bar, double c_bar, float* returns, float* off_policy_ratio, float* off_env_ratio,
+                          float* ratio, void* stream) {
+  if (!rewards || !values || !neglogp || !opp_neglogp || !dones || !last_dones || !last_values || !returns || !off_policy_ratio ||
+      !off_env_ratio || !ratio || T <= 0 || N <= 0)
+    FAIL(-1, "bad arguments");
+  hipLaunchKernelGGL(ppo_vtrace_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, rewards, values, neglogp, opp_neglogp,
+                     dones, last_dones, last_values, T, N, gamma, (float)lam, (float)rho_bar, (float)c_bar, returns, off_policy_ratio,
+                     off_env_ratio, ratio);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// advantage normalisation (model.py:180-185)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) ppo_adv_moments_kernel(const float* ret, const float* val, const int32_t* idx, int n, double* mom) {
+  __shared__ double s1[1024], s2[1024];
+  double a = 0, b = 0;
+  for (int k = threadIdx.x; k < n; k += 1024) {
+    int r = idx ? idx[k] : k;
+    double d = (double)(ret[r] - val[r]);  // float32 subtraction first, as numpy does
+    a += d; b += d * d;
+  }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { mom[0] = s1[0]; mom[1] = s2[0]; mom[2] = (double)n; }
+}
+__global__ void ppo_adv_normalize_kernel(const float* ret, const float* val, const int32_t* idx, int n, const double* mom, float* out) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double cnt = mom[2], mean = mom[0] / cnt, var = mom[1] / cnt - mean * mean;
+  if (var < 0) var = 0;
+  float m32 = (float)mean, s32 = (float)sqrt(var);
+  int r = idx ? idx[k] : k;
+  out[k] = ((ret[r] - val[r]) - m32) / (s32 + 1e-8f);
+}
+extern "C" int ppo_adv_moments(const float* returns, const float* values, const int32_t* idx, int n, double* moments, void* stream) {
+  if (!returns || !values || !moments || n <= 0) FAIL(-1, "bad arguments");
+  hipLaunchKernelGGL(ppo_adv_moments_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, returns, values, idx, n, moments);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int ppo_adv_normalize(const float* returns, const float* values, const int32_t* idx, int n, const double* moments,
+                                 float* adv_out, void* stream) {
+  if (!returns || !values || !moments || !adv_out || n <= 0) FAIL(-1, "bad arguments");
+  hipLaunchKernelGGL(ppo_adv_normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, returns, values, idx, n, moments,
+                     adv_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// training: loss + gradients
+// ---------------------------------------------------------------------------------------------------------
+struct GradArgs {
+  const float *params, *obs, *actions, *adv, *returns, *oldnlp, *weight;
+  const int32_t* idx;
+  float* slabs;       // [2][nwaves][P]   (net, wave, param) -- only the net's own ranges are written
+  double* wstats;     // [2][nwaves][8]
+  float* log_ratio;
+  int n, obs_stride, XS, nwaves;
+  float inv_count, cliprange, ent_coef, vf_coef;
+  ParamLayout L;
+};
+
+// dW[KT x 4 tiles] += Act^T[features x rows] * Delta[rows x 64]: act/delta tiles in LDS, row-major [16][stride]
+template <int KT>
+__device__ __forceinline__ void accumulate_wgrad(f32x4 (&acc)[KT][4], const float* act, int astride, const float* delta, int lane) {
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    int row = 4 * s + kq;
+    float b[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) b[ct] = delta[row * HS + ct * 16 + i];
+#pragma unroll
+    for (int ft = 0; ft < KT; ft++) {
+      float a = act[row * astride + ft * 16 + i];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) acc[ft][ct] = MFMA(a, b[ct], acc[ft][ct]);
+    }
+  }
+}
+
+// delta_in[16][HS] (LDS) times W^T -> masked by act > 0 -> delta_out (LDS); W is [64 x 64] row-major [in][out],
+// so (delta W^T)[row][f] = sum_k delta[row][k] * W[f][k].  Also accumulates the column sums of the result (bias grad).
+__device__ __forceinline__ void backprop_hidden(const float* delta_in, const float* W, const float* act, float* delta_out, float (&bsum)[4],
+                                                int lane) {
+  const int i = lane & 15, kq = lane >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
+  for (int k0 = 0; k0 < H; k0 += 4) {
+    int k = k0 + kq;
+    float a = delta_in[i * HS + k];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a, W[(ct * 16 + i) * H + k], acc[ct]);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) {
+    float s = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int o = (4 * kq + r) * HS + ct * 16 + i;
+      float d = act[o] > 0.0f ? acc[ct][r] : 0.0f;
+      delta_out[o] = d;
+      s += d;
+    }
+    bsum[ct] += s;
+  }
+}
+
+template <int KT, bool PI>
+__device__ __forceinline__ void grad_net(const GradArgs& a, float* lds, int wave_global, int lane) {
+  const ParamLayout& L = a.L;
+  const int XS = a.XS, D = L.D, A = L.A;
+  const int i = lane & 15, kq = lane >> 4;
+  float *xbuf = lds, *h1 = xbuf + 16 * XS, *h2 = h1 + 16 * HS, *d1 = h2 + 16 * HS, *d2 = d1 + 16 * HS, *dout = d2 + 16 * HS;
+  const Net net = PI ? pi_net(a.params, L) : vf_net(a.params, L);
+  f32x4 gW0[KT][4], gW1[4][4], gW2[4][1];
+#pragma unroll
+  for (int ft = 0; ft < KT; ft++)
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) gW0[ft][ct] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+  for (int ft = 0; ft < 4; ft++) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) gW1[ft][ct] = (f32x4){0, 0, 0, 0};
+    gW2[ft][0] = (f32x4){0, 0, 0, 0};
+  }
+  float gb0[4] = {0, 0, 0, 0}, gb1[4] = {0, 0, 0, 0}, gb2 = 0, glogstd = 0;
+  double st_pg = 0, st_vf = 0, st_kl = 0, st_clip = 0, st_cnt = 0;
+  const bool col = i < net.nout;
+  const float logstd = (PI && col) ? a.params[L.logstd + i] : 0.0f;
+  const float std = expf(logstd);
+  const float sum_logstd = row16_sum(logstd);
+  const int ntiles = (a.n + 15) / 16;
+  for (int tile = wave_global; tile < ntiles; tile += a.nwaves) {
+    const int r0 = tile * 16;
+    stage_x(xbuf, XS, a.obs, a.obs_stride, D, a.idx, r0, a.n, lane);
+    wave_sync();
+    f32x4 out = trunk_forward(net, xbuf, XS, D, h1, h2, lane);
+    // ---- head deltas (D layout: rows 4kq+r, column i)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int row = r0 + 4 * kq + r;
+      bool rok = row < a.n;
+      int src = rok ? (a.idx ? a.idx[row] : row) : 0;
+      float dhead = 0.0f;
+      if (PI) {
+        float m = out[r];
+        float act = (rok && col) ? a.actions[(size_t)src * A + i] : m;
+        float z = (act - m) / std;
+        if (!(rok && col)) z = 0.0f;
+        float ss = row16_sum(z * z);
+        float nlp = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
+        float old = rok ? a.oldnlp[src] : nlp;
+        float lr = old - nlp;
+        float ratio = expf(lr);
+        bool isnan_ = ratio != ratio;
+        if (isnan_) ratio = 2.0f;                                         // model.py:96
+        float adv = rok ? a.adv[row] : 0.0f, w = rok ? a.weight[src] : 0.0f;
+        float lo = 1.0f - a.cliprange, hi = 1.0f + a.cliprange;
+        float rc = fminf(fmaxf(ratio, lo), hi);
+        float l1 = -adv * ratio, l2 = -adv * rc;
+        bool first = l1 >= l2;
+        bool in_clip = ratio >= lo && ratio <= hi;
+        float dratio = w * a.inv_count * (first ? -adv : (in_clip ? -adv : 0.0f));
+        if (isnan_) dratio = 0.0f;
+        float dnlp = -dratio * ratio;
+        dhead = col ? dnlp * (-(z / std)) : 0.0f;
+        if (rok && col) glogstd += dnlp * (1.0f - z * z) - a.ent_coef * a.inv_count;
+        if (rok && i == 0) {
+          st_pg += (double)(w * fmaxf(l1, l2));
+          st_kl += (double)(nlp - old);
+          st_clip += (fabsf(ratio - 1.0f) > a.cliprange) ? 1.0 : 0.0;
+          st_cnt += 1.0;
+          if (a.log_ratio) a.log_ratio[row] = lr;
+        }
+      } else {
+        float v = out[r];
+        float R = rok ? a.returns[src] : v;
+        float dv = v - R;
+        dhead = (rok && col) ? a.vf_coef * a.inv_count * dv : 0.0f;
+        if (rok && i == 0) { st_vf += 0.5 * (double)dv * (double)dv; st_cnt += 1.0; }
+      }
+      dout[(4 * kq + r) * 18 + i] = dhead;
+      gb2 += dhead;
+    }
+    wave_sync();
+    // ---- head weight gradient: gW2[64 x nout] += h2^T * dhead  (B operand = dhead tile, 16 columns)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      int row = 4 * s + kq;
+      float b = dout[row * 18 + i];
+#pragma unroll
+      for (int ft = 0; ft < 4; ft++) gW2[ft][0] = MFMA(h2[row * HS + ft * 16 + i], b, gW2[ft][0]);
+    }
+    // ---- dh2 = dhead * W2^T, masked by h2 > 0
+    {
+      f32x4 acc[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
+      const int nk = (net.nout + 3) & ~3;
+      for (int k0 = 0; k0 < nk; k0 += 4) {
+        int k = k0 + kq;
+        float av = dout[i * 18 + k];
+        bool kok = k < net.nout;
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(av, kok ? net.w2[(ct * 16 + i) * net.nout + k] : 0.0f, acc[ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) {
+        float s = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int o = (4 * kq + r) * HS + ct * 16 + i;
+          float d = h2[o] > 0.0f ? acc[ct][r] : 0.0f;
+          d2[o] = d;
+          s += d;
+        }
+        gb1[ct] += s;
+      }
+    }
+    wave_sync();
+    accumulate_wgrad<4>(gW1, h1, HS, d2, lane);
+    backprop_hidden(d2, net.w1, h1, d1, gb0, lane);
+    wave_sync();
+    accumulate_wgrad<KT>(gW0, xbuf, XS, d1, lane);
+    wave_sync();
+  }
+  // ---- write this wave's partial gradients (slab) -- D layout: rows 4kq+r of the tile, column i
+  float* slab = a.slabs + ((size_t)(PI ? 0 : 1) * a.nwaves + wave_global) * L.P;
+  const int o_w0 = PI ? L.pi_w0 : L.vf_w0, o_b0 = PI ? L.pi_b0 : L.vf_b0, o_w1 = PI ? L.pi_w1 : L.vf_w1, o_b1 = PI ? L.pi_b1 : L.vf_b1;
+  const int o_w2 = PI ? L.pi_w : L.vf_w, o_b2 = PI ? L.pi_b : L.vf_b;
+#pragma unroll
+  for (int ft = 0; ft < KT; ft++)
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int f = ft * 16 + 4 * kq + r;
+        if (f < D) slab[o_w0 + f * H + ct * 16 + i] = gW0[ft][ct][r];
+      }
+#pragma unroll
+  for (int ft = 0; ft < 4; ft++) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) slab[o_w1 + (ft * 16 + 4 * kq + r) * H + ct * 16 + i] = gW1[ft][ct][r];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (col) slab[o_w2 + (ft * 16 + 4 * kq + r) * net.nout + i] = gW2[ft][0][r];
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) {
+    float s0 = kq_sum(gb0[ct]), s1 = kq_sum(gb1[ct]);
+    if (kq == 0) { slab[o_b0 + ct * 16 + i] = s0; slab[o_b1 + ct * 16 + i] = s1; }
+  }
+  float s2 = kq_sum(gb2), sl = kq_sum(glogstd);
+  if (kq == 0 && col) { slab[o_b2 + i] = s2; if (PI) slab[L.logstd + i] = sl; }
+  // stats: lanes with i == 0 hold per-kq partials
+  double t_pg = st_pg, t_vf = st_vf, t_kl = st_kl, t_clip = st_clip, t_cnt = st_cnt;
+  for (int o = 16; o < 64; o <<= 1) {
+    t_pg += __shfl_xor(t_pg, o, WAVE); t_vf += __shfl_xor(t_vf, o, WAVE); t_kl += __shfl_xor(t_kl, o, WAVE);
+    t_clip += __shfl_xor(t_clip, o, WAVE); t_cnt += __shfl_xor(t_cnt, o, WAVE);
+  }
+  if (lane == 0) {
+    double* ws = a.wstats + ((size_t)(PI ? 0 : 1) * a.nwaves + wave_global) * 8;
+    ws[0] = t_pg; ws[1] = t_vf; ws[2] = 0; ws[3] = t_kl; ws[4] = t_clip; ws[5] = 0; ws[6] = PI ? t_cnt : 0.0; ws[7] = 0;
+  }
+}
+
+template <int KT>
+__global__ void __launch_bounds__(256) ppo_grad_kernel(GradArgs a) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wave_global = blockIdx.x * 4 + wid;
+  float* lds = smem_f + wid * (16 * a.XS + 4 * 16 * HS + 16 * 18);
+  if (blockIdx.y == 0) grad_net<KT, true>(a, lds, wave_global, lane);
+  else grad_net<KT, false>(a, lds, wave_global, lane);
+}
+
+// grads[p] = sum over waves of the slab of the net that owns p (fixed order); stats += per-wave stats
+__global__ void ppo_grad_reduce_kernel(const float* slabs, const double* wstats, int nwaves, ParamLayout L, float* grads, double* stats) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < L.P) {
+    bool is_vf = (p >= L.vf_w0 && p < L.pi_w) || p >= L.vf_w;
+    const float* s = slabs + (size_t)(is_vf ? 1 : 0) * nwaves * L.P + p;
+    float acc = 0.0f;
+    for (int w = 0; w < nwaves; w++) acc += s[(size_t)w * L.P];
+    grads[p] = acc;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 8) {
+    double acc = 0;
+    for (int w = 0; w < 2 * nwaves; w++) acc += wstats[(size_t)w * 8 + threadIdx.x];
+    stats[threadIdx.x] += acc;
+  }
+}
+
+static int grad_nwaves(void) { return 256 * 4; }
+extern "C" size_t ppo_grad_workspace_bytes(int ob_dim, int ac_dim) {
+  ParamLayout L = make_layout(ob_dim, ac_dim);
+  return (size_t)2 * grad_nwaves() * L.P * sizeof(float) + (size_t)2 * grad_nwaves() * 8 * sizeof(double);
+}
+
+extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, int ob_dim, int ac_dim, const float* actions,
+                        const float* adv_mb, const float* returns, const float* old_neglogp, const float* is_weight, const int32_t* idx,
+                        int n, double inv_count, float cliprange, float ent_coef, float vf_coef, float* grads, double* stats,
+                        float* log_ratio_out, void* workspace, void* stream) {
+  if (!params || !obs || !actions || !adv_mb || !returns || !old_neglogp || !is_weight || !grads || !stats || !workspace || n <= 0)
+    FAIL(-1, "bad arguments");
+  if (ac_dim < 1 || ac_dim > MAXA) FAIL(-2, "ac_dim %d not in [1,%d]", ac_dim, MAXA);
+  int KT = (ob_dim + 15) / 16;
+  if (KT > 14) FAIL(-3, "ob_dim %d too large (max 224)", ob_dim);
+  GradArgs a;
+  a.params = params; a.obs = obs; a.actions = actions; a.adv = adv_mb; a.returns = returns; a.oldnlp = old_neglogp; a.weight = is_weight;
+  a.idx = idx; a.n = n; a.obs_stride = obs_stride; a.XS = x_stride(ob_dim); a.inv_count = (float)inv_count; a.cliprange = cliprange;
+  a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.log_ratio = log_ratio_out; a.L = make_layout(ob_dim, ac_dim);
+  int ntiles = (n + 15) / 16;
+  int nblocks = (ntiles + 3) / 4;
+  if (nblocks > 256) nblocks = 256;
+  a.nwaves = nblocks * 4;
+  a.slabs = (float*)workspace;
+  a.wstats = (double*)((char*)workspace + (size_t)2 * grad_nwaves() * a.L.P * sizeof(float));
+  size_t lds = (size_t)4 * (16 * a.XS + 4 * 16 * HS + 16 * 18) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  // the slabs are only partially written by each net (its own ranges); the reduce reads only those ranges
+#define LAUNCH(KTV)                                                                                                     \
+  do {                                                                                                                  \
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ppo_grad_kernel<KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(ppo_grad_kernel<KTV>, dim3(nblocks, 2), dim3(256), lds, s, a);                                  \
+  } while (0)
+  if (KT <= 8) LAUNCH(8);
+  else if (KT <= 11) LAUNCH(11);
+  else LAUNCH(14);
+#undef LAUNCH
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3((a.L.P + 255) / 256), dim3(256), 0, s, a.slabs, a.wstats, a.nwaves, a.L, grads, stats);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// clip_by_global_norm + TF1 Adam (single block: P ~ 25k)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) ppo_clip_adam_kernel(float* params, const float* grads, float* m, float* v, int P, float lr_t,
+                                                             float beta1, float beta2, float eps, float max_norm, double* stats) {
+  __shared__ double red[1024];
+  double s = 0;
+  for (int k = threadIdx.x; k < P; k += 1024) { double g = grads[k]; s += g * g; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  float norm = (float)sqrt(red[0]);
+  float scale = 1.0f;
+  if (max_norm > 0.0f) scale = max_norm / fmaxf(norm, max_norm);          // tf.clip_by_global_norm
+  if (threadIdx.x == 0 && stats) stats[7] = (double)norm;
+  for (int k = threadIdx.x; k < P; k += 1024) {
+    float g = grads[k] * scale;
+    float mk = beta1 * m[k] + (1.0f - beta1) * g;
+    float vk = beta2 * v[k] + (1.0f - beta2) * g * g;
+    m[k] = mk; v[k] = vk;
+    params[k] -= lr_t * mk / (sqrtf(vk) + eps);                            // TF1: epsilon outside the bias correction
+  }
+}
+extern "C" int ppo_clip_adam(float* params, const float* grads, float* m, float* v, int P, int t, double lr, double beta1, double beta2,
+                             double eps, double max_grad_norm, double* stats, void* stream) {
+  if (!params || !grads || !m || !v || P <= 0 || t < 1) FAIL(-1, "bad arguments");
+  double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+  hipLaunchKernelGGL(ppo_clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, params, grads, m, v, P, (float)lr_t, (float)beta1,
+                     (float)beta2, (float)eps, (float)max_grad_norm, stats);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

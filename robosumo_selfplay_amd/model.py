@@ -1,0 +1,137 @@
+"""``PPOModel`` on the HIP kernels: same constructor keywords, methods and return shapes as the reference's
+TF1 class (model.py:9-213).  Loss / optimiser arithmetic: csrc/ppo_kernels.hip."""
+import os
+
+import numpy as np
+
+from . import policies, ppo_capi
+
+
+class PPOModel(object):
+    loss_names = ["policy_loss", "value_loss", "policy_entropy", "approxkl", "clipfrac"]   # model.py:138
+
+    def __init__(self, *, policy, ob_space=None, ac_space=None, nbatch_act=None, nbatch_train=None, nsteps=None,
+                 ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, microbatch_size=None, trainable=True, model_scope="",
+                 device=0, comm=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise ppo_capi.PpoHipError("PPOModel needs a HIP device (no CPU fallback in the product path)")
+        ppo_capi.lib()
+        self._t = torch
+        self.spec = policy
+        self.scope = model_scope
+        self.sess = None
+        self.device = torch.device("cuda", int(device))
+        self.ent_coef, self.vf_coef, self.max_grad_norm = float(ent_coef), float(vf_coef), max_grad_norm
+        self.trainable = trainable
+        self.comm = comm            # torch.distributed process group (or None): gradient / moment all-reduce
+        D, A = policy.ob_dim, policy.ac_dim
+        self.P = ppo_capi.lib().ppo_param_count(D, A)
+        flat = policies.flatten_params(policies.init_param_list(D, A))
+        assert flat.size == self.P
+        self.params = torch.from_numpy(flat).to(self.device)
+        self.act_model = policies.PolicyWithValue(policy, self.params, self.device)
+        self.train_model = self.act_model
+        self.step = self.act_model.step
+        self.value = self.act_model.value
+        self.initial_state = None
+        if trainable:
+            self.m = torch.zeros(self.P, dtype=torch.float32, device=self.device)
+            self.v = torch.zeros(self.P, dtype=torch.float32, device=self.device)
+            self.t = 0
+            self.grads = torch.zeros(self.P + ppo_capi.NSTATS * 2, dtype=torch.float32, device=self.device)
+            self.stats = torch.zeros(ppo_capi.NSTATS, dtype=torch.float64, device=self.device)
+            self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
+            self.workspace = torch.empty(ppo_capi.lib().ppo_grad_workspace_bytes(D, A), dtype=torch.uint8, device=self.device)
+
+    # ---- checkpoints: list of 13 float32 arrays in TF variable order (model.py:153-177) -----------------------
+    def get_param_list(self):
+        return policies.unflatten_params(self.params.cpu().numpy(), self.spec.ob_dim, self.spec.ac_dim)
+
+    def set_param_list(self, plist):
+        shapes = policies.param_shapes(self.spec.ob_dim, self.spec.ac_dim)
+        if isinstance(plist, dict):                                    # model.py:174-175: dict keyed by TF variable name
+            plist = [plist["%s/%s:0" % (self.scope, n)] if "%s/%s:0" % (self.scope, n) in plist else plist[n]
+                     for n in policies.PARAM_NAMES]
+        assert len(plist) == len(shapes), "number of variables loaded mismatches len(variables)"
+        for p, s in zip(plist, shapes):
+            if tuple(np.shape(p)) != tuple(s):
+                raise ValueError("checkpoint tensor shape %s does not match %s" % (np.shape(p), s))
+        self.params.copy_(self._t.from_numpy(policies.flatten_params(plist)))
+
+    def save(self, save_path):
+        dirname = os.path.dirname(save_path)
+        if dirname:
+            os.makedirs(dirname, exist_ok=True)
+        import joblib
+        joblib.dump(self.get_param_list(), save_path)                  # same on-disk format as model.py:161
+
+    def load(self, load_path):
+        import joblib
+        self.set_param_list(joblib.load(os.path.expanduser(load_path)))   # only files written by save()
+
+    # ---- training (model.py:179-213) ---------------------------------------------------------------------------
+    def _dev(self, x, dtype):
+        t = self._t
+        if t.is_tensor(x):
+            return x
+        return t.as_tensor(np.ascontiguousarray(x, dtype=dtype)).to(self.device)
+
+    def train(self, lr, cliprange, obs, returns, masks, actions, values, neglogpacs, rewards, IS_weight, states=None):
+        t = self._t
+        np_in = not t.is_tensor(obs)
+        obs = self._dev(obs, np.float32)
+        ret, val = self._dev(returns, np.float32), self._dev(values, np.float32)
+        act, old, w = self._dev(actions, np.float32), self._dev(neglogpacs, np.float32), self._dev(IS_weight, np.float32)
+        out = self.train_indexed(lr, cliprange, obs, ret, act, val, old, w, None, obs.shape[0])
+        stats = out[:5]
+        if np_in:
+            return [np.float32(s) for s in stats] + [out[5].cpu().numpy(), None]
+        return list(stats) + [out[5], None]
+
+    def train_indexed(self, lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n):
+        """One optimiser step on rows ``idx`` (int32 CUDA tensor or None) of device-resident batch arrays."""
+        if not self.trainable:
+            raise RuntimeError("model built with trainable=False")
+        t = self._t
+        L = ppo_capi.lib()
+        D, A = self.spec.ob_dim, self.spec.ac_dim
+        st = t.cuda.current_stream(self.device).cuda_stream
+        ip = ppo_capi.ptr(idx)
+        if obs.stride(1) != 1:
+            raise ValueError("obs rows must have unit inner stride")
+        # advantages: returns - values, normalised over the (global) minibatch (model.py:180-185)
+        ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), st))
+        if self.comm is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.moments, group=self.comm)
+        adv = t.empty(n, dtype=t.float32, device=self.device)
+        ppo_capi.chk(L.ppo_adv_normalize(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), adv.data_ptr(), st))
+        if self.comm is not None:
+            count = float(self.moments[2].item())
+        else:
+            count = float(n)
+        self.stats.zero_()
+        log_ratio = t.empty(n, dtype=t.float32, device=self.device)
+        ppo_capi.chk(L.ppo_grad(self.params.data_ptr(), obs.data_ptr(), obs.stride(0), D, A, actions.data_ptr(), adv.data_ptr(),
+                                returns.data_ptr(), neglogpacs.data_ptr(), weights.data_ptr(), ip, n, 1.0 / count,
+                                float(cliprange), self.ent_coef, self.vf_coef, self.grads.data_ptr(), self.stats.data_ptr(),
+                                log_ratio.data_ptr(), self.workspace.data_ptr(), st))
+        if self.comm is not None:
+            import torch.distributed as dist
+            # ONE fused collective per optimiser step: [flat grad | 5 loss sums | count]
+            self.grads[self.P:self.P + ppo_capi.NSTATS] = self.stats.to(t.float32)
+            dist.all_reduce(self.grads, group=self.comm)
+            self.stats.copy_(self.grads[self.P:self.P + ppo_capi.NSTATS].to(t.float64))
+        # entropy of the distribution the loss was evaluated with (before the parameter update), model.py:69
+        logstd = self.params[self.P - 1 - policies.HIDDEN - A:self.P - 1 - policies.HIDDEN]
+        entropy_t = (logstd.double() + 0.5 * np.log(2.0 * np.pi * np.e)).sum()
+        self.t += 1
+        ppo_capi.chk(L.ppo_clip_adam(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.P,
+                                     self.t, float(lr), 0.9, 0.999, 1e-5,
+                                     float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0,
+                                     self.stats.data_ptr(), st))
+        s = self.stats.cpu().numpy()
+        cnt = s[6]
+        entropy = float(entropy_t.item())
+        return [s[0] / cnt, s[1] / cnt, entropy, s[3] / cnt, s[4] / cnt, log_ratio, s[7]]

@@ -1,0 +1,51 @@
+"""ctypes binding of include/sumo_ppo.h (csrc/libsumo_ppo.so).  No CPU fallback."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+NSTATS = 8
+FWD_PI, FWD_VF = 1, 2
+_LIB = None
+
+EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
+           "ppo_adv_normalize", "ppo_grad_workspace_bytes", "ppo_grad", "ppo_clip_adam")
+
+
+class PpoHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.environ.get("SUMO_PPO_LIB") or _build.lib_path("libsumo_ppo.so")
+        if not os.path.exists(path):
+            raise PpoHipError("%s not found: build it with `python -m robosumo_selfplay_amd.build`" % path)
+        L = C.CDLL(path)
+        vp, i32, f64, f32 = C.c_void_p, C.c_int, C.c_double, C.c_float
+        L.ppo_last_error.restype = C.c_char_p
+        L.ppo_param_count.argtypes = [i32, i32]
+        L.ppo_forward.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.ppo_reward_mix.argtypes = [vp, i32, f64, vp, i32, vp]
+        L.ppo_vtrace.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp, vp]
+        L.ppo_adv_moments.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.ppo_adv_normalize.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+        L.ppo_grad_workspace_bytes.argtypes = [i32, i32]
+        L.ppo_grad_workspace_bytes.restype = C.c_size_t
+        L.ppo_grad.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, f64, f32, f32, f32, vp, vp, vp, vp, vp]
+        L.ppo_clip_adam.argtypes = [vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, f64, vp, vp]
+        for n in EXPORTS:
+            if n not in ("ppo_last_error", "ppo_grad_workspace_bytes"):
+                getattr(L, n).restype = i32
+        _LIB = L
+    return _LIB
+
+
+def chk(rc):
+    if rc != 0:
+        raise PpoHipError("sumo_ppo error %d: %s" % (rc, lib().ppo_last_error().decode()))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,218 @@
+"""Rollout engine with the reference ``Runner``'s constructor and 15-tuple ``run(update)`` contract (runner.py:7-252).
+
+Two modes, same arithmetic (csrc/ppo_kernels.hip: reward curriculum, IS ratios, V-trace):
+  * device mode  -- ``env`` is a ``SumoVecEnv`` and the models are ``PPOModel``s: observations, actions, rewards and
+    dones never leave HBM between the env step kernel and the policy kernels; ``run`` returns CUDA tensors.
+  * host mode    -- any duck-typed VecEnv / models like the reference's: numpy per step (their API), then the collected
+    buffers go through the same kernels; ``run`` returns numpy arrays (this is what the golden-vector tests drive).
+"""
+import numpy as np
+
+from . import ppo_capi
+
+
+def sf01(arr):
+    """runner.py:255-260 (numpy or torch)"""
+    s = arr.shape
+    return arr.swapaxes(1, 2).reshape(s[0], s[1] * s[2], *s[3:])
+
+
+def sf0(arr):
+    """runner.py:263-267"""
+    return arr.swapaxes(0, 1).reshape(-1)
+
+
+def anneal_alpha(update, anneal_bound):
+    """runner.py:128-130"""
+    if update <= anneal_bound:
+        return float(np.linspace(1, 0, anneal_bound)[update - 1])
+    return 0.0
+
+
+class AbstractEnvRunner(object):
+    def __init__(self, *, env, models, nsteps, nagent, anneal_bound):
+        self.env, self.models = env, models
+        self.nenv = env.num_envs
+        self.nagent = nagent
+        self.nsteps = nsteps
+        self.anneal_bound = anneal_bound
+        self.states = [m.initial_state for m in models]
+
+
+class Runner(AbstractEnvRunner):
+    def __init__(self, *, env, models, nsteps, nagent, gamma, lam, rho_bar, c_bar, anneal_bound=500, device=None):
+        super().__init__(env=env, models=models, nsteps=nsteps, nagent=nagent, anneal_bound=anneal_bound)
+        import torch
+        if not torch.cuda.is_available():
+            raise ppo_capi.PpoHipError("Runner needs a HIP device (no CPU fallback in the product path)")
+        ppo_capi.lib()
+        self._t = torch
+        if nagent != 2:
+            raise ValueError("two-agent self-play only (runner.py assumes agents 0 and 1)")
+        self.lam, self.gamma, self.rho_bar, self.c_bar = lam, gamma, rho_bar, c_bar
+        self.device_mode = hasattr(env, "step_device") and all(hasattr(m, "act_model") and hasattr(m.act_model, "evaluate")
+                                                               for m in models)
+        self.device = getattr(env, "device", None) or device or torch.device("cuda", 0)
+        ob_shape = env.observation_space[0].shape
+        self.ob_dim = ob_shape[0]
+        if self.device_mode:
+            self.obs = env.reset_device()                               # [N, 2, D] float32, stays in HBM
+            self.dones = torch.zeros((self.nenv, 2), dtype=torch.uint8, device=self.device)
+        else:
+            self.obs = np.zeros((self.nenv, len(env.observation_space)) + ob_shape,
+                                dtype=models[0].train_model.X.dtype.name)
+            self.obs[:] = env.reset()
+            self.dones = np.array([[False for _ in range(nagent)] for _ in range(self.nenv)])
+
+    # ---- shared tail: IS ratios + V-trace on the device ---------------------------------------------------------
+    def _vtrace(self, rewards, values, nlp, onlp, dones, last_dones, last_values):
+        t = self._t
+        T, N = self.nsteps, self.nenv
+        returns = t.empty((2, T, N), dtype=t.float32, device=self.device)
+        opr = t.empty((T, N), dtype=t.float32, device=self.device)
+        oer = t.empty_like(opr)
+        ratio = t.empty_like(opr)
+        st = t.cuda.current_stream(self.device).cuda_stream
+        ppo_capi.chk(ppo_capi.lib().ppo_vtrace(rewards.data_ptr(), values.data_ptr(), nlp.data_ptr(), onlp.data_ptr(), dones.data_ptr(),
+                                               last_dones.data_ptr(), last_values.data_ptr(), T, N, float(self.gamma), float(self.lam),
+                                               float(self.rho_bar), float(self.c_bar), returns.data_ptr(), opr.data_ptr(),
+                                               oer.data_ptr(), ratio.data_ptr(), st))
+        return returns, opr, oer, ratio
+
+    def run(self, update):
+        return self._run_device(update) if self.device_mode else self._run_host(update)
+
+    # ---- device mode ------------------------------------------------------------------------------------------
+    def _run_device(self, update):
+        t = self._t
+        T, N, D = self.nsteps, self.nenv, self.ob_dim
+        env, dev = self.env, self.device
+        A = env.action_space[0].shape[0]
+        f32 = t.float32
+        mb_obs = t.empty((2, T, N, D), dtype=f32, device=dev)
+        mb_act = t.empty((2, T, N, A), dtype=f32, device=dev)
+        mb_rew = t.empty((2, T, N), dtype=f32, device=dev)
+        mb_val = t.empty((2, T, N), dtype=f32, device=dev)
+        mb_nlp = t.empty((2, T, N), dtype=f32, device=dev)
+        mb_onlp = t.empty((2, T, N), dtype=f32, device=dev)
+        mb_done = t.empty((2, T, N), dtype=t.uint8, device=dev)
+        ep_done = t.empty((T, N), dtype=t.uint8, device=dev)
+        ep_r = t.empty((T, N), dtype=t.float64, device=dev)
+        ep_l = t.empty((T, N), dtype=t.int32, device=dev)
+        learner, opp = self.models[0].act_model, self.models[1].act_model
+        PI, VF = ppo_capi.FWD_PI, ppo_capi.FWD_VF
+        alpha = anneal_alpha(update, self.anneal_bound)
+        L = ppo_capi.lib()
+        act = env.act_dev
+        scratch_a = t.empty((N, A), dtype=f32, device=dev)   # given-action echo, unused
+        for s in range(T):
+            ob = self.obs                                                # [N, 2, D] view of the env's buffer
+            mb_obs[0, s].copy_(ob[:, 0, :])
+            mb_obs[1, s].copy_(ob[:, 1, :])
+            mb_done[0, s].copy_(self.dones[:, 0])
+            mb_done[1, s].copy_(self.dones[:, 1])
+            o0, o1 = mb_obs[0, s], mb_obs[1, s]
+            # agent 0 acts with the learner; the opponent net scores that action (runner.py:67-85)
+            learner.evaluate(o0, PI | VF, out=dict(action=mb_act[0, s], neglogp=mb_nlp[0, s], value=mb_val[0, s]))
+            opp.evaluate(o0, PI, given_action=mb_act[0, s], out=dict(neglogp=mb_onlp[0, s], action=scratch_a))
+            # agent 1 acts with the opponent; the learner net evaluates value and neglogp there (runner.py:86-96)
+            opp.evaluate(o1, PI, out=dict(action=mb_act[1, s], neglogp=mb_onlp[1, s]))
+            learner.evaluate(o1, PI | VF, given_action=mb_act[1, s],
+                             out=dict(neglogp=mb_nlp[1, s], value=mb_val[1, s], action=scratch_a))
+            act[:, 0, :].copy_(mb_act[0, s])
+            act[:, 1, :].copy_(mb_act[1, s])
+            obs, info, done, er, edr, el = env.step_device(act)
+            self.obs = obs
+            self.dones = done
+            st = t.cuda.current_stream(dev).cuda_stream
+            ppo_capi.chk(L.ppo_reward_mix(info.data_ptr(), N, alpha, mb_rew[0, s].data_ptr(),
+                                          T * N, st))
+            ep_done[s].copy_(done[:, 0])
+            ep_r[s].copy_(er)
+            ep_l[s].copy_(el)
+        last_values = t.empty((2, N), dtype=f32, device=dev)
+        learner.evaluate(self.obs[:, 0, :], VF, out=dict(value=last_values[0]))   # runner.py:184: always models[0]
+        learner.evaluate(self.obs[:, 1, :], VF, out=dict(value=last_values[1]))
+        returns, opr, oer, ratio = self._vtrace(mb_rew, mb_val, mb_nlp, mb_onlp, mb_done, self.dones.contiguous(), last_values)
+        # episode infos of agent 0 (monitor.py:63-78), harvested with one host sync per rollout
+        d = ep_done.cpu().numpy().astype(bool)
+        rr, ll = ep_r.cpu().numpy(), ep_l.cpu().numpy()
+        epinfos = [{"r": round(float(rr[s, e]), 6), "l": int(ll[s, e]), "t": 0.0} for s, e in zip(*np.nonzero(d))]
+        opp_obs, opp_act = mb_obs[1], mb_act[1]
+        return (sf01(mb_obs), sf01(returns), sf01(mb_done.bool()), sf01(mb_act), sf01(mb_val), sf01(mb_nlp), sf01(mb_rew),
+                sf01(mb_onlp), sf01(opp_obs), sf01(opp_act), None, epinfos, sf0(opr), sf0(oer), sf0(ratio))
+
+    # ---- host mode ----------------------------------------------------------------------------------------------
+    def _run_host(self, update):
+        t = self._t
+        T, N, A_ = self.nsteps, self.nenv, self.nagent
+        mb_obs = [[] for _ in range(A_)]
+        mb_actions = [[] for _ in range(A_)]
+        mb_values = [[] for _ in range(A_)]
+        mb_dones = [[] for _ in range(A_)]
+        mb_nlp = [[] for _ in range(A_)]
+        mb_onlp = [[] for _ in range(A_)]
+        opp_obs, opp_act, epinfos = [], [], []
+        info_steps, env_rew_steps = [], []
+        use_info = None
+        for _ in range(T):
+            acts = []
+            for agt in range(A_):
+                o = self.obs[:, agt, :]
+                a, v, self.states[agt], nlp = self.models[agt].step(o, S=self.states[agt], M=self.dones[:, agt])
+                mb_obs[agt].append(o.copy())
+                mb_actions[agt].append(a)
+                mb_dones[agt].append(self.dones[:, agt])
+                if agt == 0:
+                    mb_values[0].append(v)
+                    mb_nlp[0].append(nlp)
+                    mb_onlp[0].append(self.models[1].act_model.action_probability(o, given_action=a))
+                else:
+                    mb_onlp[agt].append(nlp)
+                    mb_values[agt].append(self.models[0].value(o, S=self.states[agt], M=self.dones[:, agt]))
+                    mb_nlp[agt].append(self.models[0].act_model.action_probability(o, given_action=a))
+                    opp_obs.append(self.obs[:, 1, :].copy())
+                    opp_act.append(a)
+                acts.append(a)
+            self.obs[:], rewards, self.dones, infos = self.env.step(np.stack(acts, axis=1))
+            if use_info is None:
+                use_info = "shaping_reward" in infos[0][0]                # runner.py:127
+            if use_info:
+                arr = np.zeros((N, 2, 8))
+                for e in range(N):
+                    for agt in range(A_):
+                        arr[e, agt, 6] = infos[e][agt]["shaping_reward"]
+                        arr[e, agt, 3] = infos[e][agt]["main_reward"]
+                info_steps.append(arr)
+            else:
+                env_rew_steps.append(np.asarray(rewards))
+            for e in range(N):
+                ep = infos[e][0].get("episode")
+                if ep:
+                    epinfos.append(ep)
+        dev, f32 = self.device, t.float32
+        up = lambda x, dt=np.float32: t.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=dt))).to(dev)
+        mb_obs = np.asarray(mb_obs, dtype=self.obs.dtype)
+        mb_actions = np.asarray(mb_actions)
+        opp_obs = np.asarray(opp_obs, dtype=self.obs.dtype)
+        opp_act = np.asarray(opp_act)
+        mb_dones_np = np.asarray(mb_dones, dtype=bool)
+        rew = t.empty((2, T, N), dtype=f32, device=dev)
+        if use_info:
+            alpha = anneal_alpha(update, self.anneal_bound)
+            st = t.cuda.current_stream(dev).cuda_stream
+            info_dev = up(np.stack(info_steps), np.float64)               # [T, N, 2, 8]
+            for s in range(T):
+                ppo_capi.chk(ppo_capi.lib().ppo_reward_mix(info_dev[s].data_ptr(), N, alpha, rew[0, s].data_ptr(), T * N, st))
+        else:
+            rew.copy_(up(np.stack(env_rew_steps).transpose(2, 0, 1)))    # runner.py:146: rewards[:, agt], cast to float32
+        val, nlp, onlp = up(mb_values), up(mb_nlp), up(mb_onlp)
+        last_values = up(np.stack([self.models[0].value(self.obs[:, agt, :], S=self.states[agt], M=self.dones[:, agt])
+                                   for agt in range(A_)]))
+        returns, opr, oer, ratio = self._vtrace(rew, val, nlp, onlp, up(mb_dones_np, np.uint8), up(self.dones, np.uint8),
+                                                last_values)
+        n = lambda x: x.cpu().numpy()
+        mb_onlp_np = np.asarray(mb_onlp)
+        return (*map(sf01, (mb_obs, n(returns), mb_dones_np, mb_actions, np.asarray(mb_values, np.float32),
+                            np.asarray(mb_nlp, np.float32), n(rew), mb_onlp_np, opp_obs, opp_act)),
+                self.states[0], epinfos, *map(lambda x: sf0(n(x)), (opr, oer, ratio)))

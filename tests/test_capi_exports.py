@@ -55,3 +55,17 @@ def test_product_package_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("the oracle", "").replace("CPU oracle", "").lower() or f == "mjcf.py" \
                     or "import oracle" not in txt and "from oracle" not in txt and "libsumo_oracle" not in txt, f
+
+
+def test_ppo_library_exports_every_declared_symbol():
+    from robosumo_selfplay_amd import ppo_capi
+    build.build_all()
+    path = build.lib_path("libsumo_ppo.so")
+    assert os.path.exists(path)
+    L = ctypes.CDLL(path)
+    names = _declared("sumo_ppo.h")
+    assert set(names) == set(ppo_capi.EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+    L.ppo_param_count.restype = ctypes.c_int
+    assert L.ppo_param_count(121, 8) == 24529           # MLP(64,64) + copy value net on 121-d obs
