@@ -1,0 +1,200 @@
+"""PPO2 self-play driver: counterpart of the reference's ``alg_ppo.learn`` (alg_ppo.py:25-513), non-recurrent branch.
+
+Same keyword surface and per-update sequence -- opponent selection from the checkpoint directory (the checkpoint dir IS
+the opponent pool, alg_ppo.py:217-244), ``runner.run(update)``, IS-ratio hygiene (:258-280), optional opponent-data reuse
+(:325-344), ``noptepochs x nminibatches`` shuffled minibatch steps with KL early stop (:355-398), checkpoint every update
+(:459-464) -- but rollout buffers stay in HBM and each minibatch is a row-index gather inside the gradient kernel.
+Not reproduced: matplotlib histograms per update (:292-318), TF summaries.
+Multi-GPU: every rank runs this with its own env shard; ``comm`` (torch.distributed group) makes PPOModel all-reduce the
+advantage moments and the fused gradient buffer.
+"""
+import os
+import os.path as osp
+import time
+from collections import deque
+
+import numpy as np
+
+from . import dist as sdist
+from .model import PPOModel
+from .policies import build_policy
+from .runner import Runner
+
+
+def constfn(val):
+    def f(_):
+        return val
+    return f
+
+
+def safemean(xs):
+    return np.nan if len(xs) == 0 else np.mean(xs)
+
+
+def explained_variance(ypred, y):
+    """baselines/baselines/common/math_util.py:25-38"""
+    vary = np.var(y)
+    return np.nan if vary == 0 else 1 - np.var(y - ypred) / vary
+
+
+def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_data=None, eval_env=None, seed=None, nsteps=2048,
+          ent_coef=0.0, lr=3e-4, vf_coef=0.5, max_grad_norm=0.5, gamma=0.99, lam=0.95, rho_bar=1.0, c_bar=1.0, log_interval=10,
+          nminibatches=4, noptepochs=4, cliprange=0.2, save_interval=1, load_path=None, model_fn=None, update_fn=None, init_fn=None,
+          nagent=1, anneal_bound=500, vgap=None, kl_threshold=None, neglogp_threshold=10000.0, log_dir=None, comm=None,
+          verbose=True, **network_kwargs):
+    import torch
+    if seed is not None:                                                # set_global_seeds (misc_util.py:48-62)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+    lr = constfn(lr) if isinstance(lr, float) else lr
+    cliprange = constfn(cliprange) if isinstance(cliprange, float) else cliprange
+    total_timesteps = int(total_timesteps)
+    rank = 0 if comm is None else torch.distributed.get_rank(comm)
+    world = 1 if comm is None else torch.distributed.get_world_size(comm)
+    policy = build_policy(env, network, **network_kwargs)
+    nenvs = env.num_envs
+    ob_space, ac_space = env.observation_space[0], env.action_space[0]
+    nbatch = nenvs * nsteps
+    nbatch_train = nbatch // nminibatches
+    model_fn = model_fn or PPOModel
+    dev = getattr(env, "device", torch.device("cuda", 0))
+    mk = lambda scope, trainable: model_fn(policy=policy, ob_space=ob_space, ac_space=ac_space, nbatch_act=None,
+                                           nbatch_train=nbatch_train, nsteps=nsteps, ent_coef=ent_coef, vf_coef=vf_coef,
+                                           max_grad_norm=max_grad_norm, trainable=trainable, model_scope=scope, device=dev.index or 0,
+                                           comm=comm if trainable else None)
+    model = mk("model_0", True)
+    sdist.broadcast_params(model.params, comm)                          # sync_from_root (ppo2/model.py:129-131)
+    models = [model] + [mk("model_%d" % i, False) for i in range(1, nagent)]
+    model_util = mk("model_util", False)
+    log_dir = log_dir or os.environ.get("OPENAI_LOGDIR") or "/tmp/robosumo_selfplay_amd"
+    checkdir = osp.join(log_dir, "checkpoints") if world == 1 else osp.join(log_dir, "checkpoints")
+    if rank == 0:
+        model.save(osp.join(checkdir, "00000"))                          # alg_ppo.py:122-123
+    if comm is not None:
+        torch.distributed.barrier(comm)
+    if load_path is not None:
+        for m in models:
+            m.load(load_path)
+    for i, m in enumerate(models):
+        m.act_model.seed((seed or 0) * 1000 + 17 * i + rank)
+    runner = Runner(env=env, models=models, nsteps=nsteps, nagent=nagent, gamma=gamma, lam=lam, rho_bar=rho_bar, c_bar=c_bar,
+                    anneal_bound=anneal_bound)
+    epinfobuf = deque(maxlen=100)
+    if init_fn is not None:
+        init_fn()
+    tfirststart = time.perf_counter()
+    history = dict(version_gap=[], off_policy_ratio_mean=[], off_env_ratio_mean=[], total_ratio_mean=[], ppo_clip_frac=[],
+                   approxkl=[], early_stop_info=[], lossvals=[], fps=[], rollout_s=[], update_s=[])
+    nupdates = total_timesteps // nbatch
+    idx_choice = 0
+    opponent_obs = opponent_actions = None
+    for update in range(1, nupdates + 1):
+        assert nbatch % nminibatches == 0
+        tstart = time.perf_counter()
+        frac = 1.0 - (update - 1.0) / nupdates
+        lrnow, cliprangenow = lr(frac), cliprange(frac)
+        # ---- opponent selection (alg_ppo.py:191-247); rank 0 decides, everyone loads the same file
+        if update == 1:
+            runner.models[1].load(osp.join(checkdir, "00000"))
+            history["version_gap"].append(0)
+        else:
+            paths = sorted(osp.join(checkdir, f) for f in os.listdir(checkdir))
+            if opponent_mode == "random":
+                idx_choice = int(np.random.choice(update, 1)[0])
+                history["version_gap"].append(update - 1 - idx_choice)
+            elif opponent_mode == "latest":
+                idx_choice = len(paths) - 1
+            elif opponent_mode == "ours":                                # ratio-divergence sampling (:227-244)
+                ap = runner.models[1].act_model.action_probability(opponent_obs, given_action=opponent_actions)
+                sub = np.sort(np.random.choice(len(paths), 30, replace=False)) if len(paths) > 30 else np.arange(len(paths))
+                rd = []
+                for i in sub:
+                    model_util.load(paths[i])
+                    nap = model_util.act_model.action_probability(opponent_obs, given_action=opponent_actions)
+                    rd.append(float((nap / ap - 1.0).abs().mean().item()))
+                rd = np.array(rd)
+                rd = rd / rd.sum() if rd.sum() > 0 else np.full(len(rd), 1.0 / len(rd))
+                idx_choice = int(sub[np.random.choice(len(rd), 1, p=rd)[0]])
+            else:
+                raise ValueError("opponent_mode %r (the 'fix' mode needs the TF policy zoo: SURVEY.md §8(f) rank 2)" % opponent_mode)
+            if comm is not None:
+                c = torch.tensor([idx_choice], device=dev)
+                torch.distributed.broadcast(c, 0, group=comm)
+                idx_choice = int(c.item())
+            runner.models[1].load(paths[idx_choice])
+        # ---- rollout
+        obs, returns, masks, actions, values, neglogpacs, rewards, opponent_neglogpacs, opp_obs_s, opp_act_s, states, epinfos, \
+            off_policy_ratio, off_env_ratio, total_ratio = runner.run(update)
+        torch.cuda.synchronize(dev)
+        t_roll = time.perf_counter() - tstart
+        T, N = nsteps, nenvs
+        # un-scrambled opponent data for the 'ours' selector: rows = agent 1's (obs, action), env-major
+        opponent_obs, opponent_actions = obs[1], actions[1]
+        # ---- ratio hygiene (alg_ppo.py:258-280)
+        clip_ratio = rho_bar
+
+        def clean(r, key):
+            r = torch.where(torch.isnan(r), torch.full_like(r, clip_ratio), r)
+            history[key].append(float(r.mean().item()))
+            return r.clamp(0.0, clip_ratio)
+        off_policy_ratio = clean(off_policy_ratio, "off_policy_ratio_mean")
+        off_env_ratio = clean(off_env_ratio, "off_env_ratio_mean")
+        total_ratio = clean(total_ratio, "total_ratio_mean")
+        usable = torch.nonzero(neglogpacs[1] < neglogp_threshold).flatten()
+        use_opp = use_opponent_data is not None and not (vgap is not None and history["version_gap"] and history["version_gap"][-1] > vgap)
+        if not use_opp:                                                  # alg_ppo.py:325-327
+            b_obs, b_ret, b_act, b_val, b_nlp = obs[0], returns[0], actions[0], values[0], neglogpacs[0]
+            weights = torch.ones(nbatch, dtype=torch.float32, device=dev)
+        else:                                                            # :331-344
+            cat = lambda x: torch.cat([x[0], x[1][usable]], dim=0)
+            b_obs, b_ret, b_act, b_val, b_nlp = cat(obs), cat(returns), cat(actions), cat(values), cat(neglogpacs)
+            ones = torch.ones(nbatch, dtype=torch.float32, device=dev)
+            if use_opponent_data == "direct":
+                weights = torch.ones(b_obs.shape[0], dtype=torch.float32, device=dev)
+            elif use_opponent_data == "off_policy":
+                weights = torch.cat([ones, off_policy_ratio[usable]])
+            elif use_opponent_data == "both":
+                weights = torch.cat([ones, total_ratio[usable]])
+            else:
+                raise ValueError("use_opponent_data %r" % use_opponent_data)
+        b_obs = b_obs.contiguous()
+        epinfobuf.extend(epinfos)
+        # ---- minibatch SGD (alg_ppo.py:355-398)
+        nsamp = b_obs.shape[0]
+        mblossvals, early_stop, stop_info = [], False, None
+        for epoch in range(noptepochs):
+            inds = torch.from_numpy(np.random.permutation(nsamp).astype(np.int32)).to(dev)    # np.random.shuffle (:375)
+            for ii, start in enumerate(range(0, nsamp, nbatch_train)):
+                mb = inds[start:start + nbatch_train]
+                out = model.train_indexed(lrnow, cliprangenow, b_obs, b_ret, b_act, b_val, b_nlp, weights, mb, int(mb.numel()))
+                mblossvals.append(out[:5])
+                if kl_threshold is not None and out[3] > kl_threshold * 1.5:
+                    early_stop, stop_info = True, [epoch, ii]
+                    break
+            if early_stop:
+                break
+        history["early_stop_info"].append(stop_info)
+        lossvals = np.mean(np.array(mblossvals, dtype=np.float64), axis=0)
+        history["lossvals"].append(lossvals)
+        history["ppo_clip_frac"].append(lossvals[-1])
+        history["approxkl"].append(lossvals[-2])
+        torch.cuda.synchronize(dev)
+        tnow = time.perf_counter()
+        history["rollout_s"].append(t_roll)
+        history["update_s"].append(tnow - tstart - t_roll)
+        history["fps"].append(nbatch * world / (tnow - tstart))
+        if update_fn is not None:
+            update_fn(update)
+        if verbose and rank == 0 and (update % log_interval == 0 or update == 1):
+            ev = explained_variance(b_val.cpu().numpy(), b_ret.cpu().numpy())
+            print("update %d/%d  fps %.0f  rollout %.2fs  sgd %.2fs  ev %.3f  eprewmean %.2f  eplenmean %.1f  %s" % (
+                update, nupdates, history["fps"][-1], t_roll, tnow - tstart - t_roll, ev, safemean([e["r"] for e in epinfobuf]),
+                safemean([e["l"] for e in epinfobuf]), " ".join("%s %.4g" % (n, v) for n, v in zip(model.loss_names, lossvals))),
+                flush=True)
+        if save_interval and (update % save_interval == 0 or update == 1) and rank == 0:
+            model.save(osp.join(checkdir, "%.5i" % update))               # alg_ppo.py:459-464
+        if comm is not None:
+            torch.distributed.barrier(comm)
+    model.history = history
+    model.time_elapsed = time.perf_counter() - tfirststart
+    return model

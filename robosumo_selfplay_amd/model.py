@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from . import policies, ppo_capi
+from . import dist as sdist, policies, ppo_capi
 
 
 class PPOModel(object):
@@ -102,9 +102,7 @@ class PPOModel(object):
             raise ValueError("obs rows must have unit inner stride")
         # advantages: returns - values, normalised over the (global) minibatch (model.py:180-185)
         ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), st))
-        if self.comm is not None:
-            import torch.distributed as dist
-            dist.all_reduce(self.moments, group=self.comm)
+        sdist.allreduce_moments(self.moments, self.comm)
         adv = t.empty(n, dtype=t.float32, device=self.device)
         ppo_capi.chk(L.ppo_adv_normalize(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), adv.data_ptr(), st))
         if self.comm is not None:
@@ -118,10 +116,9 @@ class PPOModel(object):
                                 float(cliprange), self.ent_coef, self.vf_coef, self.grads.data_ptr(), self.stats.data_ptr(),
                                 log_ratio.data_ptr(), self.workspace.data_ptr(), st))
         if self.comm is not None:
-            import torch.distributed as dist
             # ONE fused collective per optimiser step: [flat grad | 5 loss sums | count]
             self.grads[self.P:self.P + ppo_capi.NSTATS] = self.stats.to(t.float32)
-            dist.all_reduce(self.grads, group=self.comm)
+            sdist.allreduce_fused(self.grads, self.comm)
             self.stats.copy_(self.grads[self.P:self.P + ppo_capi.NSTATS].to(t.float64))
         # entropy of the distribution the loss was evaluated with (before the parameter update), model.py:69
         logstd = self.params[self.P - 1 - policies.HIDDEN - A:self.P - 1 - policies.HIDDEN]

@@ -268,3 +268,31 @@ def test_device_rollout_and_update_smoke():
         assert np.isfinite(st[:5]).all()
     assert torch.isfinite(learner.params).all() and not torch.equal(before, learner.params)
     env.close()
+
+
+def test_learn_plumbing_config1(tmp_path):
+    """BASELINE config 1 ("8 envs, MLP, ~1k steps", plumbing): nsteps=128 -> nbatch 1024 = total_timesteps, one update of
+    6 epochs x 32 minibatches of 32.  Pass = loop runs, finite losses, checkpoints 00000/00001."""
+    from robosumo_selfplay_amd import alg_ppo, defaults
+    env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=8, seed=42)
+    kw = defaults.get_default_params("RoboSumo-Ant-vs-Ant-v0")
+    kw.update(nsteps=128)
+    model = alg_ppo.learn(network="mlp", env=env, seed=42, total_timesteps=1024, nagent=2, log_dir=str(tmp_path), verbose=False, **kw)
+    h = model.history
+    assert len(h["lossvals"]) == 1 and np.isfinite(h["lossvals"][0]).all() and model.t == 6 * 32
+    assert sorted(os.listdir(os.path.join(str(tmp_path), "checkpoints"))) == ["00000", "00001"]
+    assert h["total_ratio_mean"][0] == pytest.approx(1.0, abs=1e-3)      # update 1: opponent == checkpoint 00000 == learner
+    assert torch.isfinite(model.params).all()
+    env.close()
+
+
+def test_learn_opponent_modes_and_opponent_data(tmp_path):
+    from robosumo_selfplay_amd import alg_ppo
+    env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=16, seed=1)
+    model = alg_ppo.learn(network="mlp", env=env, seed=1, total_timesteps=16 * 16 * 3, nagent=2, log_dir=str(tmp_path), verbose=False,
+                          nsteps=16, nminibatches=4, noptepochs=2, lr=1e-3, gamma=0.995, lam=1.0, rho_bar=10.0, c_bar=1.0,
+                          opponent_mode="ours", use_opponent_data="both", value_network="copy", num_hidden=64, activation="relu",
+                          anneal_bound=1000, kl_threshold=10.0)
+    assert len(model.history["lossvals"]) == 3 and all(np.isfinite(l).all() for l in model.history["lossvals"])
+    assert len(os.listdir(os.path.join(str(tmp_path), "checkpoints"))) == 4
+    env.close()
