@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path named by BASELINE.json: vectorised RoboSumo env steps per second.
 
-A "step" is ONE pass of the hot path over one batch: one vectorised env step (5 x RK4 mj_step, game rules, rewards,
-done, auto-reset, observation write) for `--envs` environments per GPU (BASELINE configs[1]: RoboSumo Ant-vs-Ant,
-4096 envs, 1 MI355X), on synthetic inputs resident in HBM (states warmed up from the env's own reset distribution
-under N(0,1) actions).  Multi-GPU: one process per GPU (torch.distributed / RCCL), envs sharded with
+A "step" is ONE pass of the hot path over one batch: one rollout step of the PPO2 self-play Runner -- the 5 policy /
+value evaluations of reference runner.py:66-97 (4 fused MFMA launches), one vectorised env step (5 x RK4 mj_step, game
+rules, rewards, done, auto-reset, observation write) and the reward curriculum -- for `--envs` environments per GPU
+(BASELINE configs[1]: RoboSumo Ant-vs-Ant, 4096 envs, MLP(64,64), 1 MI355X).  Inputs are synthetic and resident in HBM:
+random-init networks of the reference architecture (zero-init logstd => N(0,1)-scale actions, the initial policy's law)
+and env states warmed up from the env's own reset distribution.  After the timed region one full PPO2
+update (rollout of --ppo-nsteps + noptepochs x nminibatches optimiser steps) is timed for the "+ PPO2 iters/sec" half
+of the metric and reported under config.  Multi-GPU: one process per GPU (torch.distributed / RCCL), envs sharded with
 no data-path collective -> weak scaling; value = total env-steps of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).
@@ -58,6 +62,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-envs", type=int, default=512)
     ap.add_argument("--cpu-sample-steps", type=int, default=60)
+    ap.add_argument("--ppo-nsteps", type=int, default=128, help="rollout length of the PPO2 update timed after the main region (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(os.cpu_count(), 16): a 1-GPU box's CPU share")
     args = ap.parse_args()
 
@@ -82,10 +87,24 @@ def main():
     model = mjcf.load_model(args.env_id)
     N = args.envs
     env = SumoVecEnv(args.env_id, num_envs=N, seed=1000 + rank * N, device=local_rank, model=model)
-    env.reset_device()
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    n_act = 16
-    acts = [torch.randn((N, 2, env.engine.act_stride), generator=gen, device=dev, dtype=torch.float32) for _ in range(n_act)]
+    from robosumo_selfplay_amd import defaults
+    from robosumo_selfplay_amd.model import PPOModel
+    from robosumo_selfplay_amd.policies import build_policy
+    from robosumo_selfplay_amd.runner import Runner, anneal_alpha
+    np.random.seed(0)                                    # identical random-init weights on every rank
+    hp = defaults.get_default_params(args.env_id)
+    spec = build_policy(env, "mlp", value_network=hp["value_network"], num_hidden=hp["num_hidden"], activation=hp["activation"])
+    group = dist.group.WORLD if dist is not None else None
+    learner = PPOModel(policy=spec, ent_coef=hp["ent_coef"], vf_coef=0.5, max_grad_norm=0.5, model_scope="model_0",
+                       device=local_rank, comm=group)
+    opponent = PPOModel(policy=spec, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, trainable=False, model_scope="model_1",
+                        device=local_rank)
+    opponent.set_param_list(learner.get_param_list())
+    learner.act_model.seed(1234 + rank)
+    opponent.act_model.seed(4321 + rank)
+    runner = Runner(env=env, models=[learner, opponent], nsteps=args.ppo_nsteps, nagent=2, gamma=hp["gamma"], lam=hp["lam"],
+                    rho_bar=hp["rho_bar"], c_bar=hp["c_bar"], anneal_bound=hp["anneal_bound"])
+    alpha = anneal_alpha(1, hp["anneal_bound"])
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -93,8 +112,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    ring = 8
+    B = runner._alloc_device(ring)
     for k in range(args.warmup):
-        env.step_device(acts[k % n_act])
+        runner._step_device(B, k % ring, alpha)
     torch.cuda.synchronize(dev)
     st0 = env.engine.stats()
     states = None
@@ -108,13 +129,38 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev0[k].record()
-        env.step_device(acts[k % n_act])
-        ev1[k].record()
+        runner._step_device(B, k % ring, alpha, env_events=(ev0[k], ev1[k]))
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     st1 = env.engine.stats()
+    sample_acts = [B["act"][:, k].permute(1, 0, 2).contiguous() for k in range(ring)]   # [N, 2, A] per step
+
+    # ---- "+ PPO2 iters/sec": one full update, outside the timed region above
+    ppo = None
+    if args.ppo_nsteps > 0:
+        T, nmb, nep = args.ppo_nsteps, hp["nminibatches"], hp["noptepochs"]
+        barrier()
+        tu = time.perf_counter()
+        out = runner.run(1)
+        torch.cuda.synchronize(dev)
+        t_roll = time.perf_counter() - tu
+        obs_b, ret_b, act_b, val_b, nlp_b = out[0][0].contiguous(), out[1][0], out[3][0], out[4][0], out[5][0]
+        nb = N * T
+        wts = torch.ones(nb, dtype=torch.float32, device=dev)
+        for ep in range(nep):
+            inds = torch.from_numpy(np.random.permutation(nb).astype(np.int32)).to(dev)
+            for start in range(0, nb, nb // nmb):
+                mb = inds[start:start + nb // nmb]
+                learner.train_indexed(hp["lr"], hp["cliprange"], obs_b, ret_b, act_b, val_b, nlp_b, wts, mb, int(mb.numel()))
+        barrier()
+        t_upd = time.perf_counter() - tu
+        tt = torch.tensor([t_upd, t_roll], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ppo = {"iters_per_sec": 1.0 / float(tt[0].item()), "nsteps": T, "nminibatches": nmb, "noptepochs": nep,
+               "rollout_s": float(tt[1].item()), "sgd_s": float(tt[0].item() - tt[1].item()),
+               "samples_per_iter": nb * world}
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -128,12 +174,14 @@ def main():
         achieved = B * N / (kern_ms * 1e-3) / 1e9
         nfwd = max(1.0, st1["forward"] - st0["forward"])
         out = {
-            "metric": "env-steps/sec (whole node), RoboSumo Ant-vs-Ant 4096 envs/GPU",
+            "metric": "env-steps/sec (whole node), RoboSumoAnts-v0 4096 envs, + PPO2 iters/sec",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s, %d envs per GPU, one vectorised env step (frame_skip 5 x RK4) per bench step, "
-                                   "N(0,1) actions, auto-reset on" % (args.env_id, N),
+            "config": {"workload": "%s, %d envs per GPU, MLP(64,64) policy+value: one self-play rollout step per bench step "
+                                   "(5 policy/value evaluations + env step of frame_skip 5 x RK4 + reward mix), random-init "
+                                   "networks, auto-reset on" % (args.env_id, N),
+                       "ppo2": ppo,
                        "envs_per_gpu": N, "total_envs": N * world, "parallelism": "env-shard x%d" % world,
                        "mean_contacts_per_forward": (st1["contacts"] - st0["contacts"]) / nfwd,
                        "mean_newton_iters_per_forward": (st1["newton"] - st0["newton"]) / nfwd,
@@ -145,7 +193,7 @@ def main():
         }
         if states is not None:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            cpu_acts = [a[:states[0].shape[0]].cpu().numpy() for a in acts]
+            cpu_acts = [a[:states[0].shape[0]].cpu().numpy() for a in sample_acts]
             v = cpu_baseline(model, states, cpu_acts, args.cpu_sample_steps, threads)
             out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",
                                    "sample": "%d envs x %d steps of the same warmed-up workload, OpenMP over envs"

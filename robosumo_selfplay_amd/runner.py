@@ -83,64 +83,77 @@ class Runner(AbstractEnvRunner):
         return self._run_device(update) if self.device_mode else self._run_host(update)
 
     # ---- device mode ------------------------------------------------------------------------------------------
-    def _run_device(self, update):
+    def _alloc_device(self, T):
+        """Rollout buffers [agent, time, env, ...] in HBM."""
         t = self._t
-        T, N, D = self.nsteps, self.nenv, self.ob_dim
-        env, dev = self.env, self.device
-        A = env.action_space[0].shape[0]
+        N, D, dev = self.nenv, self.ob_dim, self.device
+        A = self.env.action_space[0].shape[0]
         f32 = t.float32
-        mb_obs = t.empty((2, T, N, D), dtype=f32, device=dev)
-        mb_act = t.empty((2, T, N, A), dtype=f32, device=dev)
-        mb_rew = t.empty((2, T, N), dtype=f32, device=dev)
-        mb_val = t.empty((2, T, N), dtype=f32, device=dev)
-        mb_nlp = t.empty((2, T, N), dtype=f32, device=dev)
-        mb_onlp = t.empty((2, T, N), dtype=f32, device=dev)
-        mb_done = t.empty((2, T, N), dtype=t.uint8, device=dev)
-        ep_done = t.empty((T, N), dtype=t.uint8, device=dev)
-        ep_r = t.empty((T, N), dtype=t.float64, device=dev)
-        ep_l = t.empty((T, N), dtype=t.int32, device=dev)
+        B = dict(T=T, A=A)
+        B["obs"] = t.empty((2, T, N, D), dtype=f32, device=dev)
+        B["act"] = t.empty((2, T, N, A), dtype=f32, device=dev)
+        for k in ("rew", "val", "nlp", "onlp"):
+            B[k] = t.empty((2, T, N), dtype=f32, device=dev)
+        B["done"] = t.empty((2, T, N), dtype=t.uint8, device=dev)
+        B["ep_done"] = t.empty((T, N), dtype=t.uint8, device=dev)
+        B["ep_r"] = t.empty((T, N), dtype=t.float64, device=dev)
+        B["ep_l"] = t.empty((T, N), dtype=t.int32, device=dev)
+        B["scratch_a"] = t.empty((N, A), dtype=f32, device=dev)
+        return B
+
+    def _step_device(self, B, s, alpha, env_events=None):
+        """One rollout step (runner.py:62-151): 4 fused policy launches (the reference's 5 evaluations), env step, reward mix."""
+        t = self._t
+        env, N = self.env, self.nenv
         learner, opp = self.models[0].act_model, self.models[1].act_model
         PI, VF = ppo_capi.FWD_PI, ppo_capi.FWD_VF
-        alpha = anneal_alpha(update, self.anneal_bound)
-        L = ppo_capi.lib()
+        ob = self.obs                                                    # [N, 2, D] view of the env's buffer
+        B["obs"][0, s].copy_(ob[:, 0, :])
+        B["obs"][1, s].copy_(ob[:, 1, :])
+        B["done"][0, s].copy_(self.dones[:, 0])
+        B["done"][1, s].copy_(self.dones[:, 1])
+        o0, o1 = B["obs"][0, s], B["obs"][1, s]
+        # agent 0 acts with the learner; the opponent net scores that action (runner.py:67-85)
+        learner.evaluate(o0, PI | VF, out=dict(action=B["act"][0, s], neglogp=B["nlp"][0, s], value=B["val"][0, s]))
+        opp.evaluate(o0, PI, given_action=B["act"][0, s], out=dict(neglogp=B["onlp"][0, s], action=B["scratch_a"]))
+        # agent 1 acts with the opponent; the learner net evaluates value and neglogp there (runner.py:86-96)
+        opp.evaluate(o1, PI, out=dict(action=B["act"][1, s], neglogp=B["onlp"][1, s]))
+        learner.evaluate(o1, PI | VF, given_action=B["act"][1, s],
+                         out=dict(neglogp=B["nlp"][1, s], value=B["val"][1, s], action=B["scratch_a"]))
         act = env.act_dev
-        scratch_a = t.empty((N, A), dtype=f32, device=dev)   # given-action echo, unused
+        act[:, 0, :].copy_(B["act"][0, s])
+        act[:, 1, :].copy_(B["act"][1, s])
+        if env_events is not None:
+            env_events[0].record()
+        obs, info, done, er, edr, el = env.step_device(act)
+        if env_events is not None:
+            env_events[1].record()
+        self.obs = obs
+        self.dones = done
+        st = t.cuda.current_stream(self.device).cuda_stream
+        ppo_capi.chk(ppo_capi.lib().ppo_reward_mix(info.data_ptr(), N, alpha, B["rew"][0, s].data_ptr(), B["T"] * N, st))
+        B["ep_done"][s].copy_(done[:, 0])
+        B["ep_r"][s].copy_(er)
+        B["ep_l"][s].copy_(el)
+
+    def _run_device(self, update):
+        t = self._t
+        T, N = self.nsteps, self.nenv
+        B = self._alloc_device(T)
+        alpha = anneal_alpha(update, self.anneal_bound)
         for s in range(T):
-            ob = self.obs                                                # [N, 2, D] view of the env's buffer
-            mb_obs[0, s].copy_(ob[:, 0, :])
-            mb_obs[1, s].copy_(ob[:, 1, :])
-            mb_done[0, s].copy_(self.dones[:, 0])
-            mb_done[1, s].copy_(self.dones[:, 1])
-            o0, o1 = mb_obs[0, s], mb_obs[1, s]
-            # agent 0 acts with the learner; the opponent net scores that action (runner.py:67-85)
-            learner.evaluate(o0, PI | VF, out=dict(action=mb_act[0, s], neglogp=mb_nlp[0, s], value=mb_val[0, s]))
-            opp.evaluate(o0, PI, given_action=mb_act[0, s], out=dict(neglogp=mb_onlp[0, s], action=scratch_a))
-            # agent 1 acts with the opponent; the learner net evaluates value and neglogp there (runner.py:86-96)
-            opp.evaluate(o1, PI, out=dict(action=mb_act[1, s], neglogp=mb_onlp[1, s]))
-            learner.evaluate(o1, PI | VF, given_action=mb_act[1, s],
-                             out=dict(neglogp=mb_nlp[1, s], value=mb_val[1, s], action=scratch_a))
-            act[:, 0, :].copy_(mb_act[0, s])
-            act[:, 1, :].copy_(mb_act[1, s])
-            obs, info, done, er, edr, el = env.step_device(act)
-            self.obs = obs
-            self.dones = done
-            st = t.cuda.current_stream(dev).cuda_stream
-            ppo_capi.chk(L.ppo_reward_mix(info.data_ptr(), N, alpha, mb_rew[0, s].data_ptr(),
-                                          T * N, st))
-            ep_done[s].copy_(done[:, 0])
-            ep_r[s].copy_(er)
-            ep_l[s].copy_(el)
-        last_values = t.empty((2, N), dtype=f32, device=dev)
-        learner.evaluate(self.obs[:, 0, :], VF, out=dict(value=last_values[0]))   # runner.py:184: always models[0]
-        learner.evaluate(self.obs[:, 1, :], VF, out=dict(value=last_values[1]))
-        returns, opr, oer, ratio = self._vtrace(mb_rew, mb_val, mb_nlp, mb_onlp, mb_done, self.dones.contiguous(), last_values)
+            self._step_device(B, s, alpha)
+        learner = self.models[0].act_model
+        last_values = t.empty((2, N), dtype=t.float32, device=self.device)
+        learner.evaluate(self.obs[:, 0, :], ppo_capi.FWD_VF, out=dict(value=last_values[0]))   # runner.py:184: always models[0]
+        learner.evaluate(self.obs[:, 1, :], ppo_capi.FWD_VF, out=dict(value=last_values[1]))
+        returns, opr, oer, ratio = self._vtrace(B["rew"], B["val"], B["nlp"], B["onlp"], B["done"], self.dones.contiguous(), last_values)
         # episode infos of agent 0 (monitor.py:63-78), harvested with one host sync per rollout
-        d = ep_done.cpu().numpy().astype(bool)
-        rr, ll = ep_r.cpu().numpy(), ep_l.cpu().numpy()
+        d = B["ep_done"].cpu().numpy().astype(bool)
+        rr, ll = B["ep_r"].cpu().numpy(), B["ep_l"].cpu().numpy()
         epinfos = [{"r": round(float(rr[s, e]), 6), "l": int(ll[s, e]), "t": 0.0} for s, e in zip(*np.nonzero(d))]
-        opp_obs, opp_act = mb_obs[1], mb_act[1]
-        return (sf01(mb_obs), sf01(returns), sf01(mb_done.bool()), sf01(mb_act), sf01(mb_val), sf01(mb_nlp), sf01(mb_rew),
-                sf01(mb_onlp), sf01(opp_obs), sf01(opp_act), None, epinfos, sf0(opr), sf0(oer), sf0(ratio))
+        return (sf01(B["obs"]), sf01(returns), sf01(B["done"].bool()), sf01(B["act"]), sf01(B["val"]), sf01(B["nlp"]), sf01(B["rew"]),
+                sf01(B["onlp"]), sf01(B["obs"][1]), sf01(B["act"][1]), None, epinfos, sf0(opr), sf0(oer), sf0(ratio))
 
     # ---- host mode ----------------------------------------------------------------------------------------------
     def _run_host(self, update):
