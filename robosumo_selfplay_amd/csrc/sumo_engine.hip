@@ -47,12 +47,13 @@ struct Aux {  // derived integer tables (built on the host in build_aux)
 };
 
 struct Layout {  // LDS offsets in doubles unless noted
-  int ld;        // leading dimension of M / H (odd)
+  int ld;        // leading dimension of H (odd)
+  int mld, msize, d1;  // mass matrix: one dense block per agent tree, leading dim mld (odd); d1 = first dof of agent 1
   int maxcon, maxefc, maxcand;
   int qpos, qvel, warm, ctrl, x0, accv, acca, tmpv;
   int xpos, xquat, xipos, gaxis, xanchor, xaxis, com, cinert, cdof, abuf, cfrc;  // "kin scratch"
   int H;                                                                           // aliases kin scratch
-  int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim, col, dinv;
+  int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim;
   int cond, Jb, cpar, cW, cp, jar, Jv, D, aref;
   int i_base;  // start of int region (in doubles)
   // int region offsets (in ints, relative to int base)
@@ -285,6 +286,9 @@ struct Ctx {
 };
 
 #define S(off) (c.sm + c.P->L.off)
+// mass matrix element (i, j) of the block-diagonal storage; valid when i and j belong to the same agent tree
+#define MIDX(i, j) ((i) * c.P->L.mld + ((j) >= c.P->L.d1 ? (j) - c.P->L.d1 : (j)))
+#define SAME_TREE(i, j) (((i) >= c.P->L.d1) == ((j) >= c.P->L.d1))
 #ifdef SUMO_PROFILE
 #define PROF(k) do { long long _t = clock64(); c.prof[k] += (unsigned long long)(_t - c.tprev); c.tprev = _t; } while (0)
 #else
@@ -365,7 +369,7 @@ __device__ __forceinline__ void position_velocity(C& c) {
   const int lane = c.lane;
   const int nb = mdl.nbody, nv = mdl.nv;
   // zero M (dense) while the tree is being walked
-  for (int i = lane; i < nv * c.P->L.ld; i += WAVE) S(M)[i] = 0.0;
+  for (int i = lane; i < c.P->L.msize; i += WAVE) S(M)[i] = 0.0;
   if (lane == 0) {
     S(xpos)[0] = S(xpos)[1] = S(xpos)[2] = 0;
     S(xquat)[0] = 1; S(xquat)[1] = S(xquat)[2] = S(xquat)[3] = 0;
@@ -513,8 +517,8 @@ __device__ __forceinline__ void mass_matrix(C& c) {
     mul_inert_vec(buf, S(cinert) + 10 * MI(dof_bodyid)[i], S(cdof) + 6 * i);
     for (int j = i; j >= 0; j = MI(dof_parentid)[j]) {
       double v = dot6(S(cdof) + 6 * j, buf);
-      if (j == i) S(M)[i * ld + i] = v + MF(dof_armature)[i];
-      else { S(M)[i * ld + j] = v; S(M)[j * ld + i] = v; }
+      if (j == i) S(M)[MIDX(i, i)] = v + MF(dof_armature)[i];
+      else { S(M)[MIDX(i, j)] = v; S(M)[MIDX(j, i)] = v; }
     }
   }
   SYNC();
@@ -845,13 +849,15 @@ __device__ __forceinline__ double row_Jx(const C& c, int r, const double* x) {
   return cp[0] + ((k & 1) ? -mu : mu) * cp[1 + (k >> 1)];
 }
 
-// y_i = sum_k M[i][k] x[k]   (x in LDS)
+// y_i = sum_k M[i][k] x[k]   (x in LDS); M is block diagonal, so only the lane's own tree contributes
 template <class C>
 __device__ __forceinline__ double dense_Mx(const C& c, const double* x) {
   double acc = 0;
   if (c.lane < c.P->mdl.nv) {
-    const double* row = c.sm + c.P->L.M + c.lane * c.P->L.ld;
-    for (int k = 0; k < c.P->mdl.nv; k++) acc += row[k] * x[k];
+    const int d1 = c.P->L.d1, nv = c.P->mdl.nv;
+    const int k0 = c.lane >= d1 ? d1 : 0, k1 = c.lane >= d1 ? nv : d1;
+    const double* row = c.sm + c.P->L.M + c.lane * c.P->L.mld;
+    for (int k = k0; k < k1; k++) acc += row[k - k0] * x[k];
   }
   return acc;
 }
@@ -866,14 +872,22 @@ __device__ __forceinline__ double fast_rcp(double x) {  // v_rcp_f64 + two Newto
 // into registers, the wave runs a right-looking LDL^T entirely with v_readlane broadcasts (no LDS traffic, no barriers;
 // fully unrolled so every register index is static), forward-substitutes, transposes L through LDS once (`T`, nv x ld)
 // and back-substitutes.  Lane i holds b_i on entry and returns x_i.  *fail is wave-uniform.
-template <class C>
+template <bool BLOCKDIAG, class C>
 __device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* T, double b, int* fail) {
   constexpr int NV = C::NV;
   const int lane = c.lane, ld = c.P->L.ld;
   const int li = lane < NV ? lane : NV - 1;
   double a[NV];
+  if (BLOCKDIAG) {  // A is the block-diagonal mass matrix
 #pragma unroll
-  for (int k = 0; k < NV; k++) a[k] = A[li * ld + (k <= li ? k : li)];
+    for (int k = 0; k < NV; k++) {
+      int kk = k <= li ? k : li;
+      a[k] = SAME_TREE(li, kk) ? A[MIDX(li, kk)] : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV; k++) a[k] = A[li * ld + (k <= li ? k : li)];
+  }
   double dinv = 0;
   int bad = 0;
 #pragma unroll
@@ -1020,7 +1034,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
       unsigned e = c.ent[m];
       if (e != 0xFFFFu) {
         int i = e >> 8, jj = e & 0xFF;
-        double h = S(M)[i * ld + jj];
+        double h = SAME_TREE(i, jj) ? S(M)[MIDX(i, jj)] : 0.0;
         if (i == jj) h += S(dlim)[i];
         for (int ci = 0; ci < ncon; ci++) {
           int si = slotof[ci * nv + i], sj = slotof[ci * nv + jj];
@@ -1037,7 +1051,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
     SYNC();
     PROF(13);
     int hfail;
-    double sr = -ldl_solve_rows(c, S(H), S(H), lane < nv ? S(grad)[lane] : 0.0, &hfail);
+    double sr = -ldl_solve_rows<false>(c, S(H), S(H), lane < nv ? S(grad)[lane] : 0.0, &hfail);
     if (hfail) break;
     if (lane < nv) S(search)[lane] = sr;
     SYNC();
@@ -1107,7 +1121,7 @@ __device__ __forceinline__ void forward(C& c) {
   SYNC();
   // qacc_smooth = M^-1 qfrc_smooth
   int mfail;
-  double as = ldl_solve_rows(c, S(M), S(H), lane < nv ? S(qsm)[lane] : 0.0, &mfail);
+  double as = ldl_solve_rows<true>(c, S(M), S(H), lane < nv ? S(qsm)[lane] : 0.0, &mfail);
   if (mfail) as = 0.0;
   if (lane < nv) S(asmo)[lane] = as;
   SYNC();
@@ -1571,8 +1585,15 @@ static void build_layout(sumo_engine* E) {
   int kin1 = o;
   L.H = kin0;
   if (kin1 - kin0 < nv * L.ld) o = kin0 + nv * L.ld;
-  L.M = take(nv * L.ld); L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = take(nv); L.grad = take(nv);
-  L.search = take(nv); L.Mv = take(nv); L.x = take(nv); L.dlim = take(nv); L.col = take(2 * WAVE); L.dinv = take(WAVE);
+  {
+    int nv0 = SUMO_I(m, agent_nv)[0], nv1 = SUMO_I(m, agent_nv)[1];
+    int mx = nv0 > nv1 ? nv0 : nv1;
+    L.mld = mx | 1;
+    L.d1 = SUMO_I(m, agent_dofadr)[1];
+    L.msize = (nv0 + nv1) * L.mld;
+  }
+  L.M = take(L.msize); L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = take(nv); L.grad = take(nv);
+  L.search = take(nv); L.Mv = take(nv); L.x = take(nv); L.dlim = take(nv);
   L.cond = take(14 * L.maxcon); L.Jb = take(48 * L.maxcon); L.cpar = take(4 * L.maxcon); L.cW = take(6 * L.maxcon);
   L.cp = take(3 * L.maxcon);
   L.jar = take(L.maxefc); L.Jv = take(L.maxefc); L.D = take(L.maxefc); L.aref = take(L.maxefc);
