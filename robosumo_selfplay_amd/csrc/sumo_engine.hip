@@ -44,6 +44,8 @@ struct Aux {  // derived integer tables (built on the host in build_aux)
   int o_lvl_adr, o_lvl_body, o_child_adr, o_child, o_chain_len, o_chain, o_bchain_len, o_bchain, o_body_agent,
       o_tri_i, o_tri_j;
   int o_wgmat;  // double table: 9 per geom (valid for world geoms)
+  int o_stat_d, n_stat_d, o_stat_i, n_stat_i;  // tables copied into LDS at kernel start (see build_aux)
+  int nc, nworld;  // collision centres: bodies 0..nbody-1, then one per world geom
 };
 
 struct Layout {  // LDS offsets in doubles unless noted
@@ -55,9 +57,12 @@ struct Layout {  // LDS offsets in doubles unless noted
   int H;                                                                           // aliases kin scratch
   int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim;
   int cond, Jb, cpar, cW, cp, jar, Jv, D, aref;
+  int stat_d;    // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wpos[3*nworld] | waxis[3*nworld]
   int i_base;  // start of int region (in doubles)
   // int region offsets (in ints, relative to int base)
-  int con_b, dofidx, plist, lim_dof, lim_sign, scal;
+  int con_b, plist, prlist, lim_dof, lim_sign;
+  int b_dofidx;  // byte offset (relative to int base): signed char [16 * maxcon], dof of each Jacobian slot or -1
+  int stat_i;    // static int tables: ctype[nc] | cbody[nc] | chain[2*nbody] | chlen_agent[nbody]
   int b_slotof;  // byte offset (relative to int base, in bytes)
   int total_bytes;
 };
@@ -263,12 +268,44 @@ __device__ __forceinline__ double seg_box_dgrad(const double* cc, const double* 
 // ---------------------------------------------------------------------------------------------------------
 // the per-wave environment context
 // ---------------------------------------------------------------------------------------------------------
-struct Params { sumo_model_t mdl; Aux aux; Layout L; };  // lives in device memory; read through scalar loads
+// Per-lane constants, loaded into registers once per launch (a lane keeps the same roles -- body `lane`, dof `lane`,
+// joint `lane`, actuator `lane`, pair `lane + 64 r` -- for all 20 forward-dynamics evaluations of an env step).
+struct LaneRec {
+  // body role
+  double b_pos[3], b_quat[4], b_ipos[3], b_iquat[4], b_inertia[3], b_mass;
+  double j_pos[3], j_axis[3], j_qpos0;      // the body's hinge (bodies carry at most one joint)
+  int b_parent, b_level, b_agent, b_isfree, b_jnt, b_qadr, b_nchild, b_bchain_len, b_chain_len;
+  unsigned long long b_child;               // child body ids, one per byte, descending
+  unsigned b_bchain;                        // body ids root -> self, one per byte
+  unsigned long long b_chain;               // dof ids root -> body, one per byte
+  unsigned b_chain_own, b_chain_free;       // bit p: chain[p] belongs to this body / starts a free joint
+  // dof role
+  double d_arm, d_damp;
+  int d_body, d_pos;                        // d_pos: position of the dof in d_chain
+  unsigned long long d_chain;               // chain of the dof's body
+  // joint role
+  double jt_lo, jt_hi, jt_margin, jt_invw;
+  int jt_type, jt_qadr, jt_dadr, jt_limited, jt_body, jt_agent;
+  // actuator role
+  double a_gear, a_lo, a_hi;
+  int a_dof, pad_;
+};
+
+struct Params {  // lives in device memory; read through scalar / per-lane loads
+  sumo_model_t mdl; Aux aux; Layout L;
+  const LaneRec* lanes;     // [64]
+  const int* pair_rec;      // [PRmax*64]  c1 | c2<<8 | plane<<16 | valid<<17
+  const float* pair_bound;  // conservative (rounded-up) bounding-sphere reach: margin + rbound1 + rbound2 (plane: margin + rbound2)
+};
 
 template <int NV_>
 struct Ctx {
   static constexpr int NV = NV_;                                  // compile-time nv (register-resident factorisation)
   static constexpr int EPL = (NV_ * (NV_ + 1) / 2 + WAVE - 1) / WAVE;
+  static constexpr int PR = NV_ <= 28 ? 7 : NV_ <= 32 ? 10 : NV_ <= 36 ? 13 : NV_ <= 40 ? 17 : 21;  // rounds of 64 pairs
+  LaneRec k;            // per-lane constants (registers)
+  int prec[PR];
+  float pbound[PR];
   unsigned ent[EPL];  // lower-triangle entries assembled by this lane (i << 8 | k), entry t = lane + 64*m; 0xFFFF = none
   const Params* P;
   double* sm;    // LDS base (doubles)
@@ -296,39 +333,39 @@ struct Ctx {
 #endif
 
 // ---- position / velocity stage --------------------------------------------------------------------------
+#define BYTE_OF(word64, p) ((int)(((word64) >> (8 * (p))) & 0xFFull))
+
 template <class C>
-__device__ __forceinline__ void kin_body(C& c, int b) {
-  const sumo_model_t& mdl = c.P->mdl;
+__device__ __forceinline__ void kin_own_body(C& c) {  // lane == body id
+  const LaneRec& K = c.k;
+  const int b = c.lane, pid = K.b_parent;
   double* qpos = S(qpos);
-  int pid = MI(body_parentid)[b], ja = MI(body_jntadr)[b], jn = MI(body_jntnum)[b];
   double xp[3], xq[4], R[9], v[3];
-  if (jn == 1 && MI(jnt_type)[ja] == SUMO_JNT_FREE) {
-    double* q = qpos + MI(jnt_qposadr)[ja];
+  if (K.b_isfree) {
+    double* q = qpos + K.b_qadr;
     double qq[4] = {q[3], q[4], q[5], q[6]};
     normalize4(qq);
     q[3] = qq[0]; q[4] = qq[1]; q[5] = qq[2]; q[6] = qq[3];  // in-place normalisation, as mj_kinematics
     xp[0] = q[0]; xp[1] = q[1]; xp[2] = q[2];
     xq[0] = qq[0]; xq[1] = qq[1]; xq[2] = qq[2]; xq[3] = qq[3];
-    for (int k = 0; k < 3; k++) S(xanchor)[3 * ja + k] = xp[k];
+    for (int k = 0; k < 3; k++) S(xanchor)[3 * K.b_jnt + k] = xp[k];
   } else {
     quat2mat(R, S(xquat) + 4 * pid);
-    mulmatvec3(v, R, MF(body_pos) + 3 * b);
+    mulmatvec3(v, R, K.b_pos);
     for (int k = 0; k < 3; k++) xp[k] = S(xpos)[3 * pid + k] + v[k];
-    mulquat(xq, S(xquat) + 4 * pid, MF(body_quat) + 4 * b);
-    for (int j = ja; j < ja + jn; j++) {
+    mulquat(xq, S(xquat) + 4 * pid, K.b_quat);
+    if (K.b_jnt >= 0) {
+      const int j = K.b_jnt;
       double ql[4], anchor[3];
-      const double* jp = MF(jnt_pos) + 3 * j;
-      const double* jax = MF(jnt_axis) + 3 * j;
       quat2mat(R, xq);
-      mulmatvec3(v, R, jp);
+      mulmatvec3(v, R, K.j_pos);
       for (int k = 0; k < 3; k++) { anchor[k] = xp[k] + v[k]; S(xanchor)[3 * j + k] = anchor[k]; }
-      mulmatvec3(v, R, jax);
+      mulmatvec3(v, R, K.j_axis);
       for (int k = 0; k < 3; k++) S(xaxis)[3 * j + k] = v[k];
-      int qa = MI(jnt_qposadr)[j];
-      axisangle2quat(ql, jax, qpos[qa] - MF(qpos0)[qa]);
+      axisangle2quat(ql, K.j_axis, qpos[K.b_qadr] - K.j_qpos0);
       mulquat(xq, xq, ql);
       quat2mat(R, xq);
-      mulmatvec3(v, R, jp);
+      mulmatvec3(v, R, K.j_pos);
       for (int k = 0; k < 3; k++) xp[k] = anchor[k] - v[k];
     }
     normalize4(xq);
@@ -336,25 +373,23 @@ __device__ __forceinline__ void kin_body(C& c, int b) {
   for (int k = 0; k < 3; k++) S(xpos)[3 * b + k] = xp[k];
   for (int k = 0; k < 4; k++) S(xquat)[4 * b + k] = xq[k];
   quat2mat(R, xq);
-  mulmatvec3(v, R, MF(body_ipos) + 3 * b);
+  mulmatvec3(v, R, K.b_ipos);
   for (int k = 0; k < 3; k++) S(xipos)[3 * b + k] = xp[k] + v[k];
   double qi[4];
-  mulquat(qi, xq, MF(body_iquat) + 4 * b);
+  mulquat(qi, xq, K.b_iquat);
   quat2mat(R, qi);
   S(gaxis)[3 * b] = R[2]; S(gaxis)[3 * b + 1] = R[5]; S(gaxis)[3 * b + 2] = R[8];
 }
 
-// gather children into parents, level by level, for an array of `w` doubles per body
+// gather children into parents, level by level, for an array of `w` doubles per body (lane == body id)
 template <class C>
 __device__ __forceinline__ void gather_up(C& c, double* arr, int w) {
-  const Aux& aux = c.P->aux;
-  for (int lvl = aux.ndepth - 2; lvl >= 1; lvl--) {
-    int a0 = AI(lvl_adr)[lvl], a1 = AI(lvl_adr)[lvl + 1];
-    for (int idx = a0 + c.lane; idx < a1; idx += WAVE) {
-      int b = AI(lvl_body)[idx];
-      int c0 = AI(child_adr)[b], c1 = AI(child_adr)[b + 1];
-      for (int ci = c0; ci < c1; ci++) {
-        int ch = AI(child)[ci];
+  const LaneRec& K = c.k;
+  const int b = c.lane;
+  for (int lvl = c.P->aux.ndepth - 2; lvl >= 1; lvl--) {
+    if (K.b_level == lvl) {
+      for (int ci = 0; ci < K.b_nchild; ci++) {
+        int ch = BYTE_OF(K.b_child, ci);
         for (int k = 0; k < w; k++) arr[w * b + k] += arr[w * ch + k];
       }
     }
@@ -366,9 +401,9 @@ template <class C>
 __device__ __forceinline__ void position_velocity(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const Aux& aux = c.P->aux;
+  const LaneRec& K = c.k;
   const int lane = c.lane;
   const int nb = mdl.nbody, nv = mdl.nv;
-  // zero M (dense) while the tree is being walked
   for (int i = lane; i < c.P->L.msize; i += WAVE) S(M)[i] = 0.0;
   if (lane == 0) {
     S(xpos)[0] = S(xpos)[1] = S(xpos)[2] = 0;
@@ -378,18 +413,16 @@ __device__ __forceinline__ void position_velocity(C& c) {
   SYNC();
   PROF(0);
   for (int lvl = 1; lvl < aux.ndepth; lvl++) {
-    int a0 = AI(lvl_adr)[lvl], a1 = AI(lvl_adr)[lvl + 1];
-    for (int idx = a0 + lane; idx < a1; idx += WAVE) kin_body(c, AI(lvl_body)[idx]);
+    if (K.b_level == lvl) kin_own_body(c);
     SYNC();
   }
   PROF(1);
   // subtree CoM of each agent's root
   {
-    int b = lane;
-    double m = (b >= 1 && b < nb) ? MF(body_mass)[b] : 0.0;
-    int ag = (b >= 1 && b < nb) ? AI(body_agent)[b] : -1;
+    const bool isb = lane >= 1 && lane < nb;
     double px = 0, py = 0, pz = 0;
-    if (ag >= 0) { px = m * S(xipos)[3 * b]; py = m * S(xipos)[3 * b + 1]; pz = m * S(xipos)[3 * b + 2]; }
+    if (isb) { px = K.b_mass * S(xipos)[3 * lane]; py = K.b_mass * S(xipos)[3 * lane + 1]; pz = K.b_mass * S(xipos)[3 * lane + 2]; }
+    const int ag = isb ? K.b_agent : -1;
     for (int a = 0; a < mdl.nagent; a++) {
       double sx = wave_sum(ag == a ? px : 0.0), sy = wave_sum(ag == a ? py : 0.0), sz = wave_sum(ag == a ? pz : 0.0);
       if (lane == 0) {
@@ -401,16 +434,16 @@ __device__ __forceinline__ void position_velocity(C& c) {
   SYNC();
   // cinert per body, cdof per joint
   if (lane >= 1 && lane < nb) {
-    int b = lane, ag = AI(body_agent)[b];
-    const double* inert = MF(body_inertia) + 3 * b;
+    const int b = lane, ag = K.b_agent;
     double qi[4], R[9], dif[3], T[9];
-    mulquat(qi, S(xquat) + 4 * b, MF(body_iquat) + 4 * b);
+    mulquat(qi, S(xquat) + 4 * b, K.b_iquat);
     quat2mat(R, qi);
     for (int k = 0; k < 3; k++) dif[k] = S(xipos)[3 * b + k] - S(com)[3 * ag + k];
     for (int r = 0; r < 3; r++)
       for (int cc = 0; cc < 3; cc++)
-        T[3 * r + cc] = R[3 * r] * inert[0] * R[3 * cc] + R[3 * r + 1] * inert[1] * R[3 * cc + 1] + R[3 * r + 2] * inert[2] * R[3 * cc + 2];
-    double ms = MF(body_mass)[b];
+        T[3 * r + cc] = R[3 * r] * K.b_inertia[0] * R[3 * cc] + R[3 * r + 1] * K.b_inertia[1] * R[3 * cc + 1] +
+                        R[3 * r + 2] * K.b_inertia[2] * R[3 * cc + 2];
+    double ms = K.b_mass;
     double* res = S(cinert) + 10 * b;
     res[0] = T[0] + ms * (dif[1] * dif[1] + dif[2] * dif[2]);
     res[1] = T[4] + ms * (dif[0] * dif[0] + dif[2] * dif[2]);
@@ -422,10 +455,10 @@ __device__ __forceinline__ void position_velocity(C& c) {
     res[9] = ms;
   }
   if (lane < mdl.njnt) {
-    int j = lane, b = MI(jnt_bodyid)[j], da = MI(jnt_dofadr)[j], ag = AI(body_agent)[b];
+    const int j = lane, b = K.jt_body, da = K.jt_dadr, ag = K.jt_agent;
     double off[3];
     for (int k = 0; k < 3; k++) off[k] = S(com)[3 * ag + k] - S(xanchor)[3 * j + k];
-    if (MI(jnt_type)[j] == SUMO_JNT_FREE) {
+    if (K.jt_type == SUMO_JNT_FREE) {
       double R[9];
       quat2mat(R, S(xquat) + 4 * b);
       for (int k = 0; k < 3; k++) {
@@ -451,14 +484,15 @@ __device__ __forceinline__ void position_velocity(C& c) {
   // body velocities along each body's dof chain; a_b = sum over the body's own dofs of cdof_dot * qvel
   double cvel[6] = {0, 0, 0, 0, 0, 0};
   if (lane >= 1 && lane < nb) {
-    int b = lane;
+    const int b = lane;
     double a[6] = {0, 0, 0, 0, 0, 0}, cd[6];
     const double* qvel = S(qvel);
-    int len = AI(chain_len)[b], p = 0;
+    const int len = K.b_chain_len;
+    int p = 0;
     while (p < len) {
-      int j = AI(chain)[b * MAXCHAIN + p];
-      int own = MI(dof_bodyid)[j] == b;
-      if (MI(jnt_type)[MI(dof_jntid)[j]] == SUMO_JNT_FREE) {
+      const int j = BYTE_OF(K.b_chain, p);
+      const bool own = (K.b_chain_own >> p) & 1u;
+      if ((K.b_chain_free >> p) & 1u) {
         for (int k = 0; k < 3; k++)
           for (int q = 0; q < 6; q++) cvel[q] += S(cdof)[6 * (j + k) + q] * qvel[j + k];
         if (own)
@@ -483,16 +517,15 @@ __device__ __forceinline__ void position_velocity(C& c) {
   SYNC();
   // RNE forward: cacc along the body chain, cfrc = I*cacc + cvel x* (I*cvel)
   if (lane < nb) {
-    int b = lane;
+    const int b = lane;
     double* f = S(cfrc) + 6 * b;
     if (b == 0) { for (int q = 0; q < 6; q++) f[q] = 0; }
     else {
       const double* g = MF(opt) + SUMO_OPT_GRAVITY;
       double cacc[6] = {0, 0, 0, -g[0], -g[1], -g[2]}, t[6], t1[6];
-      int len = AI(bchain_len)[b];
-      for (int p = 0; p < len; p++) {
-        int k = AI(bchain)[b * MAXBCHAIN + p];
-        for (int q = 0; q < 6; q++) cacc[q] += S(abuf)[6 * k + q];
+      for (int p = 0; p < K.b_bchain_len; p++) {
+        int kb = (K.b_bchain >> (8 * p)) & 0xFFu;
+        for (int q = 0; q < 6; q++) cacc[q] += S(abuf)[6 * kb + q];
       }
       mul_inert_vec(f, S(cinert) + 10 * b, cacc);
       mul_inert_vec(t, S(cinert) + 10 * b, cvel);
@@ -502,22 +535,23 @@ __device__ __forceinline__ void position_velocity(C& c) {
   }
   SYNC();
   gather_up(c, S(cfrc), 6);
-  if (lane < nv) S(bias)[lane] = dot6(S(cdof) + 6 * lane, S(cfrc) + 6 * MI(dof_bodyid)[lane]);
+  if (lane < nv) S(bias)[lane] = dot6(S(cdof) + 6 * lane, S(cfrc) + 6 * K.d_body);
   PROF(3);
 }
 
 template <class C>
 __device__ __forceinline__ void mass_matrix(C& c) {
-  const sumo_model_t& mdl = c.P->mdl;
-  const int lane = c.lane, nv = mdl.nv, ld = c.P->L.ld;
+  const LaneRec& K = c.k;
+  const int lane = c.lane, nv = c.P->mdl.nv;
   gather_up(c, S(cinert), 10);  // cinert -> composite rigid body inertia, in place
   if (lane < nv) {
-    int i = lane;
+    const int i = lane;
     double buf[6];
-    mul_inert_vec(buf, S(cinert) + 10 * MI(dof_bodyid)[i], S(cdof) + 6 * i);
-    for (int j = i; j >= 0; j = MI(dof_parentid)[j]) {
+    mul_inert_vec(buf, S(cinert) + 10 * K.d_body, S(cdof) + 6 * i);
+    for (int p = K.d_pos; p >= 0; p--) {  // ancestors of dof i = its body's chain up to the dof itself
+      const int j = BYTE_OF(K.d_chain, p);
       double v = dot6(S(cdof) + 6 * j, buf);
-      if (j == i) S(M)[MIDX(i, i)] = v + MF(dof_armature)[i];
+      if (j == i) S(M)[MIDX(i, i)] = v + K.d_arm;
       else { S(M)[MIDX(i, j)] = v; S(M)[MIDX(j, i)] = v; }
     }
   }
@@ -525,20 +559,15 @@ __device__ __forceinline__ void mass_matrix(C& c) {
 }
 
 // ---- collision ---------------------------------------------------------------------------------------------
-template <class C>
-__device__ __forceinline__ void geom_center(const C& c, int g, double* p) {
-  const sumo_model_t& mdl = c.P->mdl;
-  int b = MI(geom_bodyid)[g];
-  if (b == 0) { const double* gp = MF(geom_pos) + 3 * g; p[0] = gp[0]; p[1] = gp[1]; p[2] = gp[2]; }
-  else { const double* xp = c.sm + c.P->L.xipos + 3 * b; p[0] = xp[0]; p[1] = xp[1]; p[2] = xp[2]; }
-}
-template <class C>
-__device__ __forceinline__ void geom_axis(const C& c, int g, double* a) {
-  const sumo_model_t& mdl = c.P->mdl;
-  int b = MI(geom_bodyid)[g];
-  if (b == 0) { const double* m = c.P->aux.af + c.P->aux.o_wgmat + 9 * g; a[0] = m[2]; a[1] = m[5]; a[2] = m[8]; }
-  else { const double* ga = c.sm + c.P->L.gaxis + 3 * b; a[0] = ga[0]; a[1] = ga[1]; a[2] = ga[2]; }
-}
+// "centre" index of a geom: its body id for agent geoms (one geom per moving body), nbody + w for world geom w.
+// Positions / axes of all centres live in the xipos / gaxis arrays (world entries are written once per launch).
+#define CTYPE(ci) (c.si[c.P->L.stat_i + (ci)])
+#define CBODY(ci) (c.si[c.P->L.stat_i + c.P->aux.nc + (ci)])
+#define CSIZE(ci) (c.sm + c.P->L.stat_d + 2 * (ci))
+#define CINVW(ci) (c.sm[c.P->L.stat_d + 2 * c.P->aux.nc + (ci)])
+#define WBOX(w) (c.sm + c.P->L.stat_d + 3 * c.P->aux.nc + 12 * (w))
+#define CHAINW(b) (c.si + c.P->L.stat_i + 2 * c.P->aux.nc + 2 * (b))
+#define CHLEN_AGENT(b) (c.si[c.P->L.stat_i + 2 * c.P->aux.nc + 2 * c.P->mdl.nbody + (b)])
 
 __device__ __forceinline__ void make_frame(double* f) {
   double n2 = sqrt(f[3] * f[3] + f[4] * f[4] + f[5] * f[5]);
@@ -554,34 +583,28 @@ __device__ __forceinline__ void make_frame(double* f) {
 
 template <class C>
 __device__ __forceinline__ void collision(C& c) {
-  const sumo_model_t& mdl = c.P->mdl;
-  const int lane = c.lane, np = mdl.npair;
-  int* plist = c.si + c.P->L.plist;
-  // broad phase over the static pair list; survivors are queued in `plist` (pair order preserved) and the narrow
-  // phase drains the queue whenever another round of 64 could overflow it
+  const int lane = c.lane, nb = c.P->mdl.nbody;
+  int* plist = c.si + c.P->L.plist;    // pair ids of broad-phase survivors (pair order preserved)
+  int* prlist = c.si + c.P->L.prlist;  // their packed centre records
   int ncand = 0, ncon = 0, dropped = 0;
-  for (int p0 = 0; p0 < np; p0 += WAVE) {
-    int p = p0 + lane, pass = 0;
-    if (p < np) {
-      int g1 = MI(pair_geom1)[p], g2 = MI(pair_geom2)[p];
-      double margin = MF(pair_margin)[p], p1[3], p2[3];
-      geom_center(c, g1, p1);
-      geom_center(c, g2, p2);
+#pragma unroll
+  for (int r = 0; r < C::PR; r++) {
+    const int rec = c.prec[r];
+    int pass = 0;
+    if (rec & (1 << 17)) {
+      const int c1 = rec & 0xFF, c2 = (rec >> 8) & 0xFF;
+      const double* p1 = S(xipos) + 3 * c1;
+      const double* p2 = S(xipos) + 3 * c2;
+      const double bound = (double)c.pbound[r];
       double t[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-      if (MI(geom_type)[g1] == SUMO_GEOM_PLANE) {
-        double n[3];
-        geom_axis(c, g1, n);
-        pass = !(dot3(t, n) > margin + MF(geom_rbound)[g2]);
-      } else {
-        double bound = margin + MF(geom_rbound)[g1] + MF(geom_rbound)[g2];
-        pass = !(dot3(t, t) > bound * bound);
-      }
+      if (rec & (1 << 16)) pass = !(dot3(t, S(gaxis) + 3 * c1) > bound);
+      else pass = !(dot3(t, t) > bound * bound);
     }
     unsigned long long bal = __ballot(pass);
     int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
-    if (pass) plist[pos] = p;
+    if (pass) { plist[pos] = lane + WAVE * r; prlist[pos] = rec; }
     ncand += __popcll(bal);
-    if (ncand + WAVE <= c.P->L.maxcand && p0 + WAVE < np) continue;
+    if (ncand + WAVE <= c.P->L.maxcand && r + 1 < C::PR) continue;
     SYNC();
     PROF(4);
     for (int k0 = 0; k0 < ncand; k0 += WAVE) {
@@ -592,42 +615,38 @@ __device__ __forceinline__ void collision(C& c) {
       double margin = 0;
       if (k < ncand) {
         p = plist[k];
-        int g1 = MI(pair_geom1)[p], g2 = MI(pair_geom2)[p];
-        int t1 = MI(geom_type)[g1], t2 = MI(geom_type)[g2];
-        if (t1 == SUMO_GEOM_CYLINDER) t1 = SUMO_GEOM_CAPSULE;  // border rods as capsules
-        if (t2 == SUMO_GEOM_CYLINDER) t2 = SUMO_GEOM_CAPSULE;
-        b1 = MI(geom_bodyid)[g1]; b2 = MI(geom_bodyid)[g2];
-        margin = MF(pair_margin)[p];
-        const double* s1 = MF(geom_size) + 3 * g1;
-        const double* s2 = MF(geom_size) + 3 * g2;
-        double p1[3], p2[3], a1[3], a2[3];
-        geom_center(c, g1, p1);
-        geom_center(c, g2, p2);
+        const int rc = prlist[k];
+        const int c1 = rc & 0xFF, c2 = (rc >> 8) & 0xFF;
+        const int t1 = CTYPE(c1), t2 = CTYPE(c2);  // cylinders already mapped to capsules (border rods)
+        b1 = CBODY(c1); b2 = CBODY(c2);
+        margin = c.P->mdl.fbase[c.P->mdl.o_pair_margin + p];
+        const double* s1 = CSIZE(c1);
+        const double* s2 = CSIZE(c2);
+        const double* p1 = S(xipos) + 3 * c1;
+        const double* p2 = S(xipos) + 3 * c2;
+        const double* g1 = S(gaxis) + 3 * c1;
+        const double* g2 = S(gaxis) + 3 * c2;
+        double a1[3], a2[3];
         if (t1 == SUMO_GEOM_PLANE) {
-          geom_axis(c, g1, a1);
-          if (t2 == SUMO_GEOM_SPHERE) plane_sphere(cs[0], margin, p1, a1, p2, s2[0]);
+          if (t2 == SUMO_GEOM_SPHERE) plane_sphere(cs[0], margin, p1, g1, p2, s2[0]);
           else if (t2 == SUMO_GEOM_CAPSULE) {
-            geom_axis(c, g2, a2);
             double e[3];
-            for (int q = 0; q < 3; q++) e[q] = p2[q] + a2[q] * s2[1];
-            plane_sphere(cs[0], margin, p1, a1, e, s2[0]);
-            for (int q = 0; q < 3; q++) e[q] = p2[q] - a2[q] * s2[1];
-            plane_sphere(cs[1], margin, p1, a1, e, s2[0]);
+            for (int q = 0; q < 3; q++) e[q] = p2[q] + g2[q] * s2[1];
+            plane_sphere(cs[0], margin, p1, g1, e, s2[0]);
+            for (int q = 0; q < 3; q++) e[q] = p2[q] - g2[q] * s2[1];
+            plane_sphere(cs[1], margin, p1, g1, e, s2[0]);
           }
         } else if (t1 == SUMO_GEOM_SPHERE && t2 == SUMO_GEOM_SPHERE) {
           sphere_sphere(cs[0], margin, p1, s1[0], p2, s2[0]);
         } else if (t1 == SUMO_GEOM_SPHERE && t2 == SUMO_GEOM_CAPSULE) {
-          geom_axis(c, g2, a2);
           double v[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-          double x = dot3(a2, v);
+          double x = dot3(g2, v);
           if (x > s2[1]) x = s2[1];
           if (x < -s2[1]) x = -s2[1];
-          double e[3] = {p2[0] + a2[0] * x, p2[1] + a2[1] * x, p2[2] + a2[2] * x};
+          double e[3] = {p2[0] + g2[0] * x, p2[1] + g2[1] * x, p2[2] + g2[2] * x};
           sphere_sphere(cs[0], margin, p1, s1[0], e, s2[0]);
         } else if (t1 == SUMO_GEOM_CAPSULE && t2 == SUMO_GEOM_CAPSULE) {
-          geom_axis(c, g1, a1);
-          geom_axis(c, g2, a2);
-          for (int q = 0; q < 3; q++) { a1[q] *= s1[1]; a2[q] *= s2[1]; }
+          for (int q = 0; q < 3; q++) { a1[q] = g1[q] * s1[1]; a2[q] = g2[q] * s2[1]; }
           double dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
           double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
           double det = ma * mc - mb * mb, v1[3], v2[3];
@@ -641,47 +660,47 @@ __device__ __forceinline__ void collision(C& c) {
             sphere_sphere(cs[0], margin, v1, s1[0], v2, s2[0]);
           } else {
             for (int si = 0; si < 2; si++) {
-              double s = si == 0 ? 1.0 : -1.0;
-              double x2 = (v - s * mb) / mc;
+              double sg = si == 0 ? 1.0 : -1.0;
+              double x2 = (v - sg * mb) / mc;
               if (x2 > 1) x2 = 1; else if (x2 < -1) x2 = -1;
-              for (int q = 0; q < 3; q++) { v1[q] = p1[q] + s * a1[q]; v2[q] = p2[q] + a2[q] * x2; }
+              for (int q = 0; q < 3; q++) { v1[q] = p1[q] + sg * a1[q]; v2[q] = p2[q] + a2[q] * x2; }
               if (si == 0) sphere_sphere(cs[0], margin, v1, s1[0], v2, s2[0]);
               else sphere_sphere(cs[1], margin, v1, s1[0], v2, s2[0]);
             }
           }
         } else if (t2 == SUMO_GEOM_BOX) {
-          const double* bm = c.P->aux.af + c.P->aux.o_wgmat + 9 * g2;
-          if (t1 == SUMO_GEOM_SPHERE) sphere_box(cs[0], margin, p1, s1[0], p2, bm, s2);
+          const double* bm = WBOX(c2 - nb);
+          const double* bs = bm + 9;
+          if (t1 == SUMO_GEOM_SPHERE) sphere_box(cs[0], margin, p1, s1[0], p2, bm, bs);
           else if (t1 == SUMO_GEOM_CAPSULE) {
-            geom_axis(c, g1, a1);
-            double axw[3] = {a1[0] * s1[1], a1[1] * s1[1], a1[2] * s1[1]}, e[3];
+            double axw[3] = {g1[0] * s1[1], g1[1] * s1[1], g1[2] * s1[1]}, e[3];
             for (int q = 0; q < 3; q++) e[q] = p1[q] + axw[q];
-            sphere_box(cs[0], margin, e, s1[0], p2, bm, s2);
+            sphere_box(cs[0], margin, e, s1[0], p2, bm, bs);
             for (int q = 0; q < 3; q++) e[q] = p1[q] - axw[q];
-            sphere_box(cs[1], margin, e, s1[0], p2, bm, s2);
+            sphere_box(cs[1], margin, e, s1[0], p2, bm, bs);
             double t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, cc[3], a[3];
             mulmatTvec3(cc, bm, t);
             mulmatTvec3(a, bm, axw);
-            double glo = seg_box_dgrad(cc, a, s2, -1.0), ghi = seg_box_dgrad(cc, a, s2, 1.0);
+            double glo = seg_box_dgrad(cc, a, bs, -1.0), ghi = seg_box_dgrad(cc, a, bs, 1.0);
             if (glo < 0 && ghi > 0) {
               double lo = -1, hi = 1;
               for (int it = 0; it < SEGBOX_BISECT; it++) {
                 double mid = 0.5 * (lo + hi);
-                if (seg_box_dgrad(cc, a, s2, mid) > 0) hi = mid; else lo = mid;
+                if (seg_box_dgrad(cc, a, bs, mid) > 0) hi = mid; else lo = mid;
               }
               double ts = 0.5 * (lo + hi);
               for (int q = 0; q < 3; q++) e[q] = p1[q] + ts * axw[q];
-              sphere_box(cs[2], margin, e, s1[0], p2, bm, s2);
+              sphere_box(cs[2], margin, e, s1[0], p2, bm, bs);
             }
           }
         }
       }
       int act[3], n = 0;
-  #pragma unroll
+#pragma unroll
       for (int q = 0; q < 3; q++) { act[q] = cs[q].ok && (cs[q].dist < margin); n += act[q]; }
       int total, base = wave_excl_scan(n, lane, &total);
       int slot = ncon + base;
-  #pragma unroll
+#pragma unroll
       for (int q = 0; q < 3; q++) {
         if (act[q]) {
           if (slot < c.P->L.maxcon) {
@@ -742,29 +761,28 @@ __device__ __forceinline__ double row_params(double timestep, const double* solr
 template <class C>
 __device__ __forceinline__ void make_constraint(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
-  const Aux& aux = c.P->aux;
+  const LaneRec& K = c.k;
   const int lane = c.lane, nv = mdl.nv, ncon = c.ncon;
   const double timestep = MF(opt)[SUMO_OPT_TIMESTEP];
   const double def_solref[2] = {0.02, 1.0};
   const double def_solimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
   int* lim_dof = c.si + c.P->L.lim_dof;
   double* lim_sign = (double*)(c.si + c.P->L.lim_sign);
-  // joint limits (lower side first, then upper, joints in order)
+  // joint limits (lower side first, then upper, joints in order); lane == joint id
   int nact = 0, act_lo = 0, act_hi = 0;
-  double dlo = 0, dhi = 0, jm = 0;
-  int j = lane;
-  if (j < mdl.njnt && MI(jnt_type)[j] == SUMO_JNT_HINGE && MI(jnt_limited)[j]) {
-    double value = S(qpos)[MI(jnt_qposadr)[j]];
-    jm = MF(jnt_margin)[j];
-    dlo = value - MF(jnt_range)[2 * j];
-    dhi = MF(jnt_range)[2 * j + 1] - value;
+  double dlo = 0, dhi = 0;
+  const double jm = K.jt_margin;
+  if (lane < mdl.njnt && K.jt_type == SUMO_JNT_HINGE && K.jt_limited) {
+    double value = S(qpos)[K.jt_qadr];
+    dlo = value - K.jt_lo;
+    dhi = K.jt_hi - value;
     act_lo = dlo < jm; act_hi = dhi < jm;
     nact = act_lo + act_hi;
   }
   int nlim, base = wave_excl_scan(nact, lane, &nlim);
   if (nact) {
-    int dof = MI(jnt_dofadr)[j], r = base;
-    double diag = MF(dof_invweight0)[dof];
+    int dof = K.jt_dadr, r = base;
+    double diag = K.jt_invw;
     if (act_lo) {
       double B, kt, R = row_params(timestep, def_solref, def_solimp, dlo, jm, diag, &B, &kt);
       lim_dof[r] = dof; lim_sign[r] = 1.0; S(D)[r] = 1.0 / R; S(Jv)[r] = B; S(jar)[r] = kt; r++;
@@ -782,13 +800,16 @@ __device__ __forceinline__ void make_constraint(C& c) {
     const int* cb = c.si + c.P->L.con_b + 4 * ci;
     int p = cb[2];
     double mu = MF(pair_friction)[3 * p];
-    double tran = MF(body_invweight0)[2 * cb[0]] + MF(body_invweight0)[2 * cb[1]];
+    double pm = MF(pair_margin)[p], pg = MF(pair_gap)[p];
+    double sr[2] = {MF(pair_solref)[2 * p], MF(pair_solref)[2 * p + 1]};
+    double si_[5];
+    for (int q = 0; q < 5; q++) si_[q] = MF(pair_solimp)[5 * p + q];
+    double tran = CINVW(cb[0]) + CINVW(cb[1]);   // body ids double as centre ids (world body 0 -> 0)
     double diag = tran + mu * mu * tran, B, kt;
-    double margin = MF(pair_margin)[p] - MF(pair_gap)[p];
-    double R = row_params(timestep, MF(pair_solref) + 2 * p, MF(pair_solimp) + 5 * p, cd[0], margin, diag, &B, &kt);
+    double R = row_params(timestep, sr, si_, cd[0], pm - pg, diag, &B, &kt);
     double Rpy = 2 * mu * mu * R;
     if (Rpy < MINVAL) Rpy = MINVAL;
-    S(cpar)[4 * ci] = mu;
+    S(cpar)[ci] = mu;
     for (int k = 0; k < 4; k++) { int r = nlim + 4 * ci + k; S(D)[r] = 1.0 / Rpy; S(Jv)[r] = B; S(jar)[r] = kt; }
   }
   PROF(6);
@@ -801,16 +822,24 @@ __device__ __forceinline__ void make_constraint(C& c) {
     int ci = idx >> 4, s = idx & 15, side = s >> 3, pos = s & 7;
     const int* cb = c.si + c.P->L.con_b + 4 * ci;
     int body = side ? cb[1] : cb[0], other = side ? cb[0] : cb[1];
-    int dof = -1;
+    int dof = -1, ag = 0;
     double j0 = 0, j1 = 0, j2 = 0;
-    if (body != 0 && pos < AI(chain_len)[body]) {
-      dof = AI(chain)[body * MAXCHAIN + pos];
-      if (other != 0 && aux.pic[other * nv + dof] >= 0) dof = -1;  // shared ancestor dof: contributions cancel
+    if (body != 0) {
+      int la = CHLEN_AGENT(body);
+      ag = la >> 8;
+      if (pos < (la & 0xFF)) {
+        const int* cw = CHAINW(body);
+        dof = ((unsigned)cw[pos >> 2] >> (8 * (pos & 3))) & 0xFF;
+        // a dof shared by both bodies' root paths sits at the same chain position: its contributions cancel
+        if (other != 0 && pos < (CHLEN_AGENT(other) & 0xFF)) {
+          const int* ow = CHAINW(other);
+          if ((int)(((unsigned)ow[pos >> 2] >> (8 * (pos & 3))) & 0xFF) == dof) dof = -1;
+        }
+      }
     }
     if (dof >= 0) {
       const double* cd = S(cond) + 14 * ci;
       const double* cdf = S(cdof) + 6 * dof;
-      int ag = AI(body_agent)[body];
       double off[3] = {cd[1] - S(com)[3 * ag], cd[2] - S(com)[3 * ag + 1], cd[3] - S(com)[3 * ag + 2]}, t[3];
       cross3(t, cdf, off);
       t[0] += cdf[3]; t[1] += cdf[4]; t[2] += cdf[5];
@@ -818,7 +847,7 @@ __device__ __forceinline__ void make_constraint(C& c) {
       j0 = sg * dot3(cd + 4, t); j1 = sg * dot3(cd + 7, t); j2 = sg * dot3(cd + 10, t);
       slotof[ci * nv + dof] = (unsigned char)s;
     }
-    c.si[c.P->L.dofidx + idx] = dof;
+    ((signed char*)c.sb)[c.P->L.b_dofidx + idx] = (signed char)dof;
     double* Jb = S(Jb) + 48 * ci;
     Jb[s] = j0; Jb[16 + s] = j1; Jb[32 + s] = j2;
   }
@@ -832,7 +861,7 @@ __device__ __forceinline__ void contact_Jx(C& c, const double* x) {
   for (int idx = c.lane; idx < 3 * c.ncon; idx += WAVE) {
     int ci = idx / 3, a = idx - 3 * ci;
     const double* Jb = S(Jb) + 48 * ci + 16 * a;
-    const int* di = c.si + c.P->L.dofidx + 16 * ci;
+    const signed char* di = (const signed char*)c.sb + c.P->L.b_dofidx + 16 * ci;
     double acc = 0;
     for (int s = 0; s < 16; s++) { int d = di[s]; if (d >= 0) acc += Jb[s] * x[d]; }
     S(cp)[idx] = acc;
@@ -844,7 +873,7 @@ template <class C>
 __device__ __forceinline__ double row_Jx(const C& c, int r, const double* x) {
   if (r < c.nlim) return ((const double*)(c.si + c.P->L.lim_sign))[r] * x[(c.si + c.P->L.lim_dof)[r]];
   int q = r - c.nlim, ci = q >> 2, k = q & 3;
-  double mu = c.sm[c.P->L.cpar + 4 * ci];
+  double mu = c.sm[c.P->L.cpar + ci];
   const double* cp = c.sm + c.P->L.cp + 3 * ci;
   return cp[0] + ((k & 1) ? -mu : mu) * cp[1 + (k >> 1)];
 }
@@ -982,7 +1011,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
     iters++;
     // ---- per-contact force / weight summaries of the active set
     for (int ci = lane; ci < ncon; ci += WAVE) {
-      double mu = S(cpar)[4 * ci], f[4], dact[4];
+      double mu = S(cpar)[ci], f[4], dact[4];
       for (int k = 0; k < 4; k++) {
         int r = nlim + 4 * ci + k;
         double j = S(jar)[r], Dr = S(D)[r];
@@ -1110,13 +1139,13 @@ __device__ __forceinline__ void forward(C& c) {
   mass_matrix(c);  // last user of the kinematic scratch; H may overwrite it from here on
   PROF(9);
   // smooth forces: passive (damping) - bias + actuation
-  if (lane < nv) S(qsm)[lane] = -MF(dof_damping)[lane] * S(qvel)[lane] - S(bias)[lane];
+  if (lane < nv) S(qsm)[lane] = -c.k.d_damp * S(qvel)[lane] - S(bias)[lane];
   SYNC();
   if (lane < mdl.nu) {
-    double u = S(ctrl)[lane], lo = MF(actuator_ctrlrange)[2 * lane], hi = MF(actuator_ctrlrange)[2 * lane + 1];
-    if (u < lo) u = lo;
-    if (u > hi) u = hi;
-    S(qsm)[MI(actuator_dofid)[lane]] += MF(actuator_gear)[lane] * u;  // one motor per dof in these scenes
+    double u = S(ctrl)[lane];
+    if (u < c.k.a_lo) u = c.k.a_lo;
+    if (u > c.k.a_hi) u = c.k.a_hi;
+    S(qsm)[c.k.a_dof] += c.k.a_gear * u;  // one motor per dof in these scenes
   }
   SYNC();
   // qacc_smooth = M^-1 qfrc_smooth
@@ -1138,11 +1167,10 @@ __device__ __forceinline__ void forward(C& c) {
 // qpos '+'= h * vel  (vel in LDS), one lane per joint
 template <class C>
 __device__ __forceinline__ void integrate_pos(C& c, double* qpos, const double* vel, double h) {
-  const sumo_model_t& mdl = c.P->mdl;
-  int j = c.lane;
-  if (j < mdl.njnt) {
-    int qa = MI(jnt_qposadr)[j], da = MI(jnt_dofadr)[j];
-    if (MI(jnt_type)[j] == SUMO_JNT_FREE) {
+  const LaneRec& K = c.k;
+  if (c.lane < c.P->mdl.njnt) {
+    const int qa = K.jt_qadr, da = K.jt_dadr;
+    if (K.jt_type == SUMO_JNT_FREE) {
       for (int k = 0; k < 3; k++) qpos[qa + k] += h * vel[da + k];
       double ax[3] = {vel[da + 3], vel[da + 4], vel[da + 5]}, qr[4], q[4] = {qpos[qa + 3], qpos[qa + 4], qpos[qa + 5], qpos[qa + 6]};
       double ang = h * normalize3(ax);
@@ -1293,6 +1321,18 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
     int t = c.lane + WAVE * m;
     c.ent[m] = t < P->aux.ntri ? (unsigned)((P->aux.ai[P->aux.o_tri_i + t] << 8) | P->aux.ai[P->aux.o_tri_j + t]) : 0xFFFFu;
   }
+  c.k = P->lanes[c.lane];
+#pragma unroll
+  for (int r = 0; r < C::PR; r++) { c.prec[r] = P->pair_rec[c.lane + WAVE * r]; c.pbound[r] = P->pair_bound[c.lane + WAVE * r]; }
+  // static tables -> LDS (once per launch); world centres into the tail of xipos / gaxis
+  for (int i = c.lane; i < P->aux.n_stat_d; i += WAVE) smem[P->L.stat_d + i] = P->aux.af[P->aux.o_stat_d + i];
+  for (int i = c.lane; i < P->aux.n_stat_i; i += WAVE) c.si[P->L.stat_i + i] = P->aux.ai[P->aux.o_stat_i + i];
+  {
+    const int nb = P->mdl.nbody, nw = P->aux.nworld, nc = P->aux.nc;
+    const double* wpos = P->aux.af + P->aux.o_stat_d + 3 * nc + 12 * nw;
+    for (int i = c.lane; i < 3 * nw; i += WAVE) { smem[P->L.xipos + 3 * nb + i] = wpos[i]; smem[P->L.gaxis + 3 * nb + i] = wpos[3 * nw + i]; }
+  }
+  __syncthreads();
   c.ncon = c.nlim = c.nefc = c.ndropped = 0;
   c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = 0;
 #ifdef SUMO_PROFILE
@@ -1477,6 +1517,12 @@ struct sumo_engine {
   Aux aux;
   Layout L;
   Params* d_params = nullptr;
+  LaneRec* d_lanes = nullptr;
+  int* d_pair_rec = nullptr;
+  float* d_pair_bound = nullptr;
+  std::vector<LaneRec> lanes;
+  std::vector<int> pair_rec;
+  std::vector<float> pair_bound;
   void* d_blob = nullptr;
   int* d_ai = nullptr;
   double* d_af = nullptr;
@@ -1558,6 +1604,135 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
   A.o_wgmat = 0;
   af.assign((size_t)9 * m->ngeom, 0.0);
   for (int g = 0; g < m->ngeom; g++) quat2mat_h(&af[9 * g], SUMO_F(m, geom_quat) + 4 * g);
+
+  // ---- collision centres: body ids for agent geoms, nbody + w for world geom w
+  const int* gbody = SUMO_I(m, geom_bodyid);
+  const int* gtype = SUMO_I(m, geom_type);
+  int nworld = SUMO_I(m, body_geomadr)[1] - SUMO_I(m, body_geomadr)[0];
+  int nc = nb + nworld;
+  if (nc > 255) FAIL(-20, "too many collision centres");
+  A.nc = nc; A.nworld = nworld;
+  std::vector<int> cen_of_geom(m->ngeom, 0), geom_of_cen(nc, -1);
+  for (int g = 0; g < m->ngeom; g++) {
+    int ci = gbody[g] == 0 ? nb + (g - SUMO_I(m, body_geomadr)[0]) : gbody[g];
+    cen_of_geom[g] = ci; geom_of_cen[ci] = g;
+  }
+  // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wpos[3*nworld] | waxis[3*nworld]
+  A.o_stat_d = (int)af.size();
+  {
+    std::vector<double> sd((size_t)3 * nc + 18 * nworld, 0.0);
+    for (int ci = 0; ci < nc; ci++) {
+      int g = geom_of_cen[ci];
+      if (g >= 0) { sd[2 * ci] = SUMO_F(m, geom_size)[3 * g]; sd[2 * ci + 1] = SUMO_F(m, geom_size)[3 * g + 1]; }
+      int body = ci < nb ? ci : 0;
+      sd[2 * nc + ci] = SUMO_F(m, body_invweight0)[2 * body];
+    }
+    for (int w = 0; w < nworld; w++) {
+      int g = SUMO_I(m, body_geomadr)[0] + w;
+      double R[9];
+      quat2mat_h(R, SUMO_F(m, geom_quat) + 4 * g);
+      double* wb = &sd[3 * nc + 12 * w];
+      for (int k = 0; k < 9; k++) wb[k] = R[k];
+      for (int k = 0; k < 3; k++) wb[9 + k] = SUMO_F(m, geom_size)[3 * g + k];
+      for (int k = 0; k < 3; k++) sd[3 * nc + 12 * nworld + 3 * w + k] = SUMO_F(m, geom_pos)[3 * g + k];
+      sd[3 * nc + 15 * nworld + 3 * w + 0] = R[2]; sd[3 * nc + 15 * nworld + 3 * w + 1] = R[5]; sd[3 * nc + 15 * nworld + 3 * w + 2] = R[8];
+    }
+    A.n_stat_d = (int)sd.size();
+    af.insert(af.end(), sd.begin(), sd.end());
+  }
+  // static int tables: ctype[nc] | cbody[nc] | chain words [2*nb] | chlen_agent[nb]
+  {
+    std::vector<int> si((size_t)2 * nc + 3 * nb, 0);
+    for (int ci = 0; ci < nc; ci++) {
+      int g = geom_of_cen[ci];
+      int t = g >= 0 ? gtype[g] : -1;
+      if (t == SUMO_GEOM_CYLINDER) t = SUMO_GEOM_CAPSULE;  // border rods collide as capsules
+      si[ci] = t; si[nc + ci] = ci < nb ? ci : 0;
+    }
+    for (int b = 0; b < nb; b++) {
+      unsigned w0 = 0, w1 = 0;
+      for (int p = 0; p < chain_len[b]; p++) {
+        unsigned d = (unsigned)chain[b * MAXCHAIN + p];
+        if (p < 4) w0 |= d << (8 * p); else w1 |= d << (8 * (p - 4));
+      }
+      si[2 * nc + 2 * b] = (int)w0; si[2 * nc + 2 * b + 1] = (int)w1;
+      si[2 * nc + 2 * nb + b] = chain_len[b] | ((body_agent[b] < 0 ? 0 : body_agent[b]) << 8);
+    }
+    A.o_stat_i = push_tbl(si);
+    A.n_stat_i = (int)si.size();
+  }
+  // ---- per-lane constants
+  E->lanes.assign(WAVE, LaneRec());
+  const int* jbody = SUMO_I(m, jnt_bodyid);
+  for (int l = 0; l < WAVE; l++) {
+    LaneRec& K = E->lanes[l];
+    memset(&K, 0, sizeof K);
+    K.b_jnt = -1; K.b_level = -1; K.b_agent = 0;
+    if (l < nb) {
+      int b = l;
+      for (int k = 0; k < 3; k++) { K.b_pos[k] = SUMO_F(m, body_pos)[3 * b + k]; K.b_ipos[k] = SUMO_F(m, body_ipos)[3 * b + k]; K.b_inertia[k] = SUMO_F(m, body_inertia)[3 * b + k]; }
+      for (int k = 0; k < 4; k++) { K.b_quat[k] = SUMO_F(m, body_quat)[4 * b + k]; K.b_iquat[k] = SUMO_F(m, body_iquat)[4 * b + k]; }
+      K.b_mass = SUMO_F(m, body_mass)[b];
+      K.b_parent = parent[b]; K.b_level = depth[b]; K.b_agent = body_agent[b] < 0 ? 0 : body_agent[b];
+      int jn = SUMO_I(m, body_jntnum)[b], ja = SUMO_I(m, body_jntadr)[b];
+      if (jn > 1) FAIL(-21, "body %d has %d joints; the engine supports at most one per body", b, jn);
+      if (jn == 1) {
+        K.b_jnt = ja;
+        K.b_isfree = SUMO_I(m, jnt_type)[ja] == SUMO_JNT_FREE;
+        K.b_qadr = SUMO_I(m, jnt_qposadr)[ja];
+        for (int k = 0; k < 3; k++) { K.j_pos[k] = SUMO_F(m, jnt_pos)[3 * ja + k]; K.j_axis[k] = SUMO_F(m, jnt_axis)[3 * ja + k]; }
+        K.j_qpos0 = SUMO_F(m, qpos0)[K.b_qadr];
+      }
+      int c0 = child_adr[b], c1 = child_adr[b + 1];
+      K.b_nchild = c1 - c0;
+      if (K.b_nchild > 8) FAIL(-22, "body %d has more than 8 children", b);
+      for (int q = 0; q < K.b_nchild; q++) K.b_child |= (unsigned long long)child[c0 + q] << (8 * q);
+      K.b_bchain_len = bchain_len[b];
+      for (int q = 0; q < bchain_len[b]; q++) K.b_bchain |= (unsigned)bchain[b * MAXBCHAIN + q] << (8 * q);
+      K.b_chain_len = chain_len[b];
+      for (int q = 0; q < chain_len[b]; q++) {
+        int d = chain[b * MAXCHAIN + q];
+        K.b_chain |= (unsigned long long)d << (8 * q);
+        if (SUMO_I(m, dof_bodyid)[d] == b) K.b_chain_own |= 1u << q;
+        int jt = SUMO_I(m, dof_jntid)[d];
+        if (SUMO_I(m, jnt_type)[jt] == SUMO_JNT_FREE && SUMO_I(m, jnt_dofadr)[jt] == d) K.b_chain_free |= 1u << q;
+      }
+    }
+    if (l < nv) {
+      int d = l, b = SUMO_I(m, dof_bodyid)[d];
+      K.d_arm = SUMO_F(m, dof_armature)[d]; K.d_damp = SUMO_F(m, dof_damping)[d]; K.d_body = b;
+      K.d_pos = pic[(size_t)b * nv + d];
+      for (int q = 0; q < chain_len[b]; q++) K.d_chain |= (unsigned long long)chain[b * MAXCHAIN + q] << (8 * q);
+    }
+    if (l < m->njnt) {
+      int j = l;
+      K.jt_type = SUMO_I(m, jnt_type)[j]; K.jt_qadr = SUMO_I(m, jnt_qposadr)[j]; K.jt_dadr = SUMO_I(m, jnt_dofadr)[j];
+      K.jt_limited = SUMO_I(m, jnt_limited)[j]; K.jt_body = jbody[j]; K.jt_agent = body_agent[jbody[j]] < 0 ? 0 : body_agent[jbody[j]];
+      K.jt_lo = SUMO_F(m, jnt_range)[2 * j]; K.jt_hi = SUMO_F(m, jnt_range)[2 * j + 1]; K.jt_margin = SUMO_F(m, jnt_margin)[j];
+      K.jt_invw = SUMO_F(m, dof_invweight0)[K.jt_dadr];
+    }
+    if (l < m->nu) {
+      K.a_dof = SUMO_I(m, actuator_dofid)[l]; K.a_gear = SUMO_F(m, actuator_gear)[l];
+      K.a_lo = SUMO_F(m, actuator_ctrlrange)[2 * l]; K.a_hi = SUMO_F(m, actuator_ctrlrange)[2 * l + 1];
+    }
+  }
+  // ---- packed pair records for the broad phase
+  {
+    int PR = nv <= 28 ? 7 : nv <= 32 ? 10 : nv <= 36 ? 13 : nv <= 40 ? 17 : 21;
+    if (m->npair > PR * WAVE) FAIL(-23, "%d collision pairs exceed the %d the nv=%d kernel variant holds", m->npair, PR * WAVE, nv);
+    E->pair_rec.assign((size_t)PR * WAVE, 0);
+    E->pair_bound.assign((size_t)PR * WAVE, 0.0f);
+    for (int p = 0; p < m->npair; p++) {
+      int g1 = SUMO_I(m, pair_geom1)[p], g2 = SUMO_I(m, pair_geom2)[p];
+      int plane = gtype[g1] == SUMO_GEOM_PLANE;
+      double bound = SUMO_F(m, pair_margin)[p] + SUMO_F(m, geom_rbound)[g2] + (plane ? 0.0 : SUMO_F(m, geom_rbound)[g1]);
+      float bf = (float)bound;
+      while ((double)bf < bound) bf = nextafterf(bf, INFINITY);   // conservative: the broad phase may only over-include
+      bf = nextafterf(bf, INFINITY);
+      E->pair_rec[p] = cen_of_geom[g1] | (cen_of_geom[g2] << 8) | (plane << 16) | (1 << 17);
+      E->pair_bound[p] = bf;
+    }
+  }
   return 0;
 }
 
@@ -1572,19 +1747,22 @@ static void build_layout(sumo_engine* E) {
   const char* mc = getenv("SUMO_MAXCON");
   if (mc && atoi(mc) > 0) L.maxcon = atoi(mc);
   L.maxefc = 4 * L.maxcon + 2 * nhinge;
-  L.maxcand = 128;  // queue of broad-phase survivors, drained by the narrow phase before it can overflow
+  L.maxcand = 96;  // queue of broad-phase survivors, drained by the narrow phase before it can overflow
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
   L.qpos = take(nq); L.qvel = take(nv); L.warm = take(nv); L.ctrl = take(nu);
   L.x0 = take(nq + nv); L.accv = take(nv); L.acca = take(nv); L.tmpv = take(nv);
   // kinematic scratch (dead once the mass matrix is built) -- H aliases its start
   int kin0 = o;
-  L.xpos = take(3 * nb); L.xquat = take(4 * nb); L.xipos = take(3 * nb); L.gaxis = take(3 * nb);
+  const int nc = E->aux.nc;
+  L.xpos = take(3 * nb); L.xquat = take(4 * nb);
   L.xanchor = take(3 * nj); L.xaxis = take(3 * nj); L.com = take(3 * m->nagent);
   L.cinert = take(10 * nb); L.cdof = take(6 * nv); L.abuf = take(6 * nb); L.cfrc = take(6 * nb);
-  int kin1 = o;
   L.H = kin0;
-  if (kin1 - kin0 < nv * L.ld) o = kin0 + nv * L.ld;
+  if (o - kin0 < nv * L.ld) o = kin0 + nv * L.ld;
+  // centre positions / axes: bodies (rewritten every forward) then world geoms (static) -- must survive H
+  L.xipos = take(3 * nc); L.gaxis = take(3 * nc);
+  L.stat_d = take(E->aux.n_stat_d);
   {
     int nv0 = SUMO_I(m, agent_nv)[0], nv1 = SUMO_I(m, agent_nv)[1];
     int mx = nv0 > nv1 ? nv0 : nv1;
@@ -1592,22 +1770,23 @@ static void build_layout(sumo_engine* E) {
     L.d1 = SUMO_I(m, agent_dofadr)[1];
     L.msize = (nv0 + nv1) * L.mld;
   }
-  L.M = take(L.msize); L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = take(nv); L.grad = take(nv);
-  L.search = take(nv); L.Mv = take(nv); L.x = take(nv); L.dlim = take(nv);
-  L.cond = take(14 * L.maxcon); L.Jb = take(48 * L.maxcon); L.cpar = take(4 * L.maxcon); L.cW = take(6 * L.maxcon);
+  L.M = take(L.msize); L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = take(nv);
+  L.search = take(nv); L.Mv = 0; L.x = take(nv); L.dlim = take(nv);
+  L.cond = take(14 * L.maxcon); L.Jb = take(48 * L.maxcon); L.cpar = take(L.maxcon); L.cW = take(6 * L.maxcon);
   L.cp = take(3 * L.maxcon);
   L.jar = take(L.maxefc); L.Jv = take(L.maxefc); L.D = take(L.maxefc); L.aref = take(L.maxefc);
   L.i_base = o;
   int io = 0;
   auto itake = [&](int n) { int r = io; io += n; return r; };
-  L.con_b = itake(4 * L.maxcon); L.dofidx = itake(16 * L.maxcon); L.plist = itake(L.maxcand);
+  L.con_b = itake(4 * L.maxcon); L.plist = itake(L.maxcand); L.prlist = itake(L.maxcand);
+  L.stat_i = itake(E->aux.n_stat_i);
   L.lim_dof = itake(2 * nhinge);
   if (io & 1) io++;
   L.lim_sign = itake(2 * 2 * nhinge);  // doubles stored in the int region (2 ints each), 8-byte aligned
-  L.scal = itake(8);
   L.b_slotof = io * 4;
-  int bytes_slot = L.maxcon * nv;
-  L.total_bytes = o * 8 + io * 4 + ((bytes_slot + 15) & ~15);
+  int bytes_slot = (L.maxcon * nv + 15) & ~15;
+  L.b_dofidx = L.b_slotof + bytes_slot;
+  L.total_bytes = o * 8 + io * 4 + bytes_slot + 16 * L.maxcon;
 }
 
 extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, int device, sumo_handle_t* out) {
@@ -1651,9 +1830,16 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
   E->dm = E->hm;
   E->dm.ibase = (const int32_t*)((const char*)E->d_blob + ((const char*)E->hm.ibase - E->blob.data()));
   E->dm.fbase = (const double*)((const char*)E->d_blob + ((const char*)E->hm.fbase - E->blob.data()));
+  HIPCHK(hipMalloc((void**)&E->d_lanes, E->lanes.size() * sizeof(LaneRec)));
+  HIPCHK(hipMemcpy(E->d_lanes, E->lanes.data(), E->lanes.size() * sizeof(LaneRec), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&E->d_pair_rec, E->pair_rec.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(E->d_pair_rec, E->pair_rec.data(), E->pair_rec.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&E->d_pair_bound, E->pair_bound.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(E->d_pair_bound, E->pair_bound.data(), E->pair_bound.size() * sizeof(float), hipMemcpyHostToDevice));
   {
     Params hp;
     hp.mdl = E->dm; hp.aux = E->aux; hp.L = E->L;
+    hp.lanes = E->d_lanes; hp.pair_rec = E->d_pair_rec; hp.pair_bound = E->d_pair_bound;
     HIPCHK(hipMalloc((void**)&E->d_params, sizeof(Params)));
     HIPCHK(hipMemcpy(E->d_params, &hp, sizeof(Params), hipMemcpyHostToDevice));
   }
@@ -1691,7 +1877,7 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
 extern "C" int sumo_destroy(sumo_handle_t E) {
   if (!E) return 0;
   (void)hipSetDevice(E->device);
-  (void)hipFree(E->d_params); (void)hipFree(E->d_blob); (void)hipFree(E->d_ai); (void)hipFree(E->d_af); (void)hipFree(E->d_pic); (void)hipFree(E->d_state);
+  (void)hipFree(E->d_params); (void)hipFree(E->d_lanes); (void)hipFree(E->d_pair_rec); (void)hipFree(E->d_pair_bound); (void)hipFree(E->d_blob); (void)hipFree(E->d_ai); (void)hipFree(E->d_af); (void)hipFree(E->d_pic); (void)hipFree(E->d_state);
   (void)hipFree(E->d_counters); (void)hipFree(E->d_seeds); (void)hipFree(E->d_stats);
   delete E;
   return 0;
