@@ -52,15 +52,18 @@ struct Layout {  // LDS offsets in doubles unless noted
   int ld;        // leading dimension of H (odd)
   int mld, msize, d1;  // mass matrix: one dense block per agent tree, leading dim mld (odd); d1 = first dof of agent 1
   int maxcon, maxefc, maxcand;
+  int warm_mode;  // 0: MuJoCo semantics (solver starts from qacc_warmstart of the previous mj_step); 1: RK stages 2-4 start
+                  // from the previous stage's solution (same optimum within the solver tolerance, fewer Newton iterations)
   int qpos, qvel, warm, ctrl, x0, accv, acca, tmpv;
   int xpos, xquat, xipos, gaxis, xanchor, xaxis, com, cinert, cdof, abuf, cfrc;  // "kin scratch"
   int H;                                                                           // aliases kin scratch
   int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim;
+  int cmask;     // per dof: 64-bit mask of the contacts whose Jacobian touches the dof
   int cond, Jb, cpar, cW, cp, jar, Jv, D, aref;
   int stat_d;    // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wpos[3*nworld] | waxis[3*nworld]
   int i_base;  // start of int region (in doubles)
   // int region offsets (in ints, relative to int base)
-  int con_b, plist, prlist, lim_dof, lim_sign;
+  int con_b, plist, prlist, lim_dof, lim_sign, limrow;  // limrow[dof] = first limit row | count << 8
   int b_dofidx;  // byte offset (relative to int base): signed char [16 * maxcon], dof of each Jacobian slot or -1
   int stat_i;    // static int tables: ctype[nc] | cbody[nc] | chain[2*nbody] | chlen_agent[nbody]
   int b_slotof;  // byte offset (relative to int base, in bytes)
@@ -313,7 +316,7 @@ struct Ctx {
   unsigned char* sb;  // LDS byte region (slotof)
   int lane;
   // per-forward scalars (wave-uniform)
-  int ncon, nlim, nefc, ndropped;
+  int ncon, nlim, nefc, ndropped, use_prev;
 #ifdef SUMO_PROFILE
   long long tprev;
   unsigned long long prof[20];
@@ -780,8 +783,11 @@ __device__ __forceinline__ void make_constraint(C& c) {
     nact = act_lo + act_hi;
   }
   int nlim, base = wave_excl_scan(nact, lane, &nlim);
+  if (lane < nv) { (c.si + c.P->L.limrow)[lane] = 0; ((unsigned long long*)S(cmask))[lane] = 0ull; }
+  SYNC();
   if (nact) {
     int dof = K.jt_dadr, r = base;
+    (c.si + c.P->L.limrow)[dof] = base | (nact << 8);
     double diag = K.jt_invw;
     if (act_lo) {
       double B, kt, R = row_params(timestep, def_solref, def_solimp, dlo, jm, diag, &B, &kt);
@@ -846,6 +852,7 @@ __device__ __forceinline__ void make_constraint(C& c) {
       double sg = side ? 1.0 : -1.0;
       j0 = sg * dot3(cd + 4, t); j1 = sg * dot3(cd + 7, t); j2 = sg * dot3(cd + 10, t);
       slotof[ci * nv + dof] = (unsigned char)s;
+      atomicOr((unsigned long long*)S(cmask) + dof, 1ull << ci);
     }
     ((signed char*)c.sb)[c.P->L.b_dofidx + idx] = (signed char)dof;
     double* Jb = S(Jb) + 48 * ci;
@@ -979,8 +986,9 @@ __device__ __forceinline__ void newton_solve(C& c) {
     return;
   }
   const unsigned char* slotof = c.sb + c.P->L.b_slotof;
-  // ---- warm start: better of qacc_warmstart and qacc_smooth
-  if (lane < nv) x[lane] = S(warm)[lane];
+  // ---- warm start: better of qacc_warmstart (or, in warm_mode 1, the previous RK stage's qacc still held in x) and
+  // qacc_smooth
+  if (!c.use_prev && lane < nv) x[lane] = S(warm)[lane];
   SYNC();
   double Ma = dense_Mx(c, x);
   contact_Jx(c, x);
@@ -1034,20 +1042,19 @@ __device__ __forceinline__ void newton_solve(C& c) {
     double g = 0;
     if (lane < nv) {
       double qc = 0, dl = 0;
-      const int* lim_dof = c.si + c.P->L.lim_dof;
       const double* lim_sign = (const double*)(c.si + c.P->L.lim_sign);
-      for (int r = 0; r < nlim; r++)
-        if (lim_dof[r] == lane) {
-          double j = S(jar)[r];
-          if (j < 0) { qc += lim_sign[r] * (-S(D)[r] * j); dl += S(D)[r]; }
-        }
-      for (int ci = 0; ci < ncon; ci++) {
+      const int lr = (c.si + c.P->L.limrow)[lane];
+      for (int q = 0; q < (lr >> 8); q++) {
+        int r = (lr & 0xFF) + q;
+        double j = S(jar)[r];
+        if (j < 0) { qc += lim_sign[r] * (-S(D)[r] * j); dl += S(D)[r]; }
+      }
+      for (unsigned long long mk = ((const unsigned long long*)S(cmask))[lane]; mk; mk &= mk - 1) {
+        int ci = __builtin_ctzll(mk);
         int s = slotof[ci * nv + lane];
-        if (s != 0xFF) {
-          const double* Jb = S(Jb) + 48 * ci;
-          const double* cp = S(cp) + 3 * ci;
-          qc += Jb[s] * cp[0] + Jb[16 + s] * cp[1] + Jb[32 + s] * cp[2];
-        }
+        const double* Jb = S(Jb) + 48 * ci;
+        const double* cp = S(cp) + 3 * ci;
+        qc += Jb[s] * cp[0] + Jb[16 + s] * cp[1] + Jb[32 + s] * cp[2];
       }
       g = Ma - S(qsm)[lane] - qc;
       S(grad)[lane] = g;
@@ -1057,24 +1064,40 @@ __device__ __forceinline__ void newton_solve(C& c) {
     PROF(12);
     if (scale * sqrt(gn) < tol) break;
     SYNC();
-    // ---- Hessian H = M + J^T diag(D_active) J, lower triangle: entry-major gather (every lane a few entries)
+    // ---- Hessian H = M + J^T diag(D_active) J, lower triangle: entry-major gather (every lane a few entries).
+    // All loads of the mass-matrix / mask words are issued before any store so they pipeline.
+    {
+      const unsigned long long* cm = (const unsigned long long*)S(cmask);
+      double hreg[C::EPL];
+      unsigned long long mreg[C::EPL];
 #pragma unroll
-    for (int m = 0; m < C::EPL; m++) {
-      unsigned e = c.ent[m];
-      if (e != 0xFFFFu) {
-        int i = e >> 8, jj = e & 0xFF;
+      for (int m = 0; m < C::EPL; m++) {
+        unsigned e = c.ent[m];
+        int i = e == 0xFFFFu ? 0 : (int)(e >> 8), jj = e == 0xFFFFu ? 0 : (int)(e & 0xFF);
         double h = SAME_TREE(i, jj) ? S(M)[MIDX(i, jj)] : 0.0;
         if (i == jj) h += S(dlim)[i];
-        for (int ci = 0; ci < ncon; ci++) {
+        hreg[m] = h;
+        mreg[m] = e == 0xFFFFu ? 0ull : (cm[i] & cm[jj]);
+      }
+#pragma unroll
+      for (int m = 0; m < C::EPL; m++) {
+        unsigned e = c.ent[m];
+        int i = e >> 8, jj = e & 0xFF;
+        double h = hreg[m];
+        for (unsigned long long mk = mreg[m]; mk; mk &= mk - 1) {
+          int ci = __builtin_ctzll(mk);
           int si = slotof[ci * nv + i], sj = slotof[ci * nv + jj];
-          if (si != 0xFF && sj != 0xFF) {
-            const double* Jb = S(Jb) + 48 * ci;
-            const double* W = S(cW) + 6 * ci;
-            double a0 = Jb[si], a1 = Jb[16 + si], a2 = Jb[32 + si], b0 = Jb[sj], b1 = Jb[16 + sj], b2 = Jb[32 + sj];
-            h += a0 * (W[0] * b0 + W[1] * b1 + W[2] * b2) + a1 * (W[1] * b0 + W[3] * b1) + a2 * (W[2] * b0 + W[4] * b2);
-          }
+          const double* Jb = S(Jb) + 48 * ci;
+          const double* W = S(cW) + 6 * ci;
+          double a0 = Jb[si], a1 = Jb[16 + si], a2 = Jb[32 + si], b0 = Jb[sj], b1 = Jb[16 + sj], b2 = Jb[32 + sj];
+          h += a0 * (W[0] * b0 + W[1] * b1 + W[2] * b2) + a1 * (W[1] * b0 + W[3] * b1) + a2 * (W[2] * b0 + W[4] * b2);
         }
-        S(H)[i * ld + jj] = h;
+        hreg[m] = h;
+      }
+#pragma unroll
+      for (int m = 0; m < C::EPL; m++) {
+        unsigned e = c.ent[m];
+        if (e != 0xFFFFu) S(H)[(e >> 8) * ld + (e & 0xFF)] = hreg[m];
       }
     }
     SYNC();
@@ -1194,6 +1217,7 @@ __device__ __forceinline__ void mj_steps(C& c, int nsteps) {
   const double h = MF(opt)[SUMO_OPT_TIMESTEP];
   for (int sub = 0; sub < 4 * nsteps; sub++) {
     const int stage = sub & 3;
+    c.use_prev = (c.P->L.warm_mode == 1 && stage != 0) ? 1 : 0;
     forward(c);
     if (stage == 0) {
       if (lane < nq) S(x0)[lane] = S(qpos)[lane];
@@ -1333,7 +1357,7 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
     for (int i = c.lane; i < 3 * nw; i += WAVE) { smem[P->L.xipos + 3 * nb + i] = wpos[i]; smem[P->L.gaxis + 3 * nb + i] = wpos[3 * nw + i]; }
   }
   __syncthreads();
-  c.ncon = c.nlim = c.nefc = c.ndropped = 0;
+  c.ncon = c.nlim = c.nefc = c.ndropped = c.use_prev = 0;
   c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = 0;
 #ifdef SUMO_PROFILE
   for (int k = 0; k < 20; k++) c.prof[k] = 0;
@@ -1746,7 +1770,9 @@ static void build_layout(sumo_engine* E) {
   L.maxcon = nv <= 28 ? 24 : (nv <= 36 ? 32 : 40);
   const char* mc = getenv("SUMO_MAXCON");
   if (mc && atoi(mc) > 0) L.maxcon = atoi(mc);
+  if (L.maxcon > 64) L.maxcon = 64;  // per-dof contact masks are 64 bits wide
   L.maxefc = 4 * L.maxcon + 2 * nhinge;
+  { const char* wm = getenv("SUMO_WARM_MODE"); L.warm_mode = wm ? atoi(wm) : 0; }
   L.maxcand = 96;  // queue of broad-phase survivors, drained by the narrow phase before it can overflow
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
@@ -1771,7 +1797,7 @@ static void build_layout(sumo_engine* E) {
     L.msize = (nv0 + nv1) * L.mld;
   }
   L.M = take(L.msize); L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = take(nv);
-  L.search = take(nv); L.Mv = 0; L.x = take(nv); L.dlim = take(nv);
+  L.search = take(nv); L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv);
   L.cond = take(14 * L.maxcon); L.Jb = take(48 * L.maxcon); L.cpar = take(L.maxcon); L.cW = take(6 * L.maxcon);
   L.cp = take(3 * L.maxcon);
   L.jar = take(L.maxefc); L.Jv = take(L.maxefc); L.D = take(L.maxefc); L.aref = take(L.maxefc);
@@ -1781,6 +1807,7 @@ static void build_layout(sumo_engine* E) {
   L.con_b = itake(4 * L.maxcon); L.plist = itake(L.maxcand); L.prlist = itake(L.maxcand);
   L.stat_i = itake(E->aux.n_stat_i);
   L.lim_dof = itake(2 * nhinge);
+  L.limrow = itake(nv);
   if (io & 1) io++;
   L.lim_sign = itake(2 * 2 * nhinge);  // doubles stored in the int region (2 ints each), 8-byte aligned
   L.b_slotof = io * 4;
