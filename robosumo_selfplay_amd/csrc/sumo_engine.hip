@@ -101,19 +101,35 @@ struct StepArgs {
 // ---------------------------------------------------------------------------------------------------------
 // small math
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double x) {  // v_rcp_f64 + two Newton steps (~1 ulp)
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {  // v_rsq_f64 + two Newton steps (~1 ulp)
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
 __device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void cross3(double* r, const double* a, const double* b) {
   double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   r[0] = x; r[1] = y; r[2] = z;
 }
 __device__ __forceinline__ double normalize3(double* v) {
-  double n = sqrt(dot3(v, v));
-  if (n < MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; } else { v[0] /= n; v[1] /= n; v[2] /= n; }
-  return n;
+  double s = dot3(v, v);
+  if (s < MINVAL * MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; return sqrt(s); }
+  double r = fast_rsqrt(s);
+  v[0] *= r; v[1] *= r; v[2] *= r;
+  return s * r;
 }
 __device__ __forceinline__ void normalize4(double* q) {
-  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
+  double s = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (s < MINVAL * MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  double r = fast_rsqrt(s);
+  q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
 }
 __device__ __forceinline__ void mulquat(double* r, const double* a, const double* b) {
   double t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
@@ -139,8 +155,9 @@ __device__ __forceinline__ void mulmatTvec3(double* r, const double* m, const do
   r[0] = x; r[1] = y; r[2] = z;
 }
 __device__ __forceinline__ void axisangle2quat(double* q, const double* axis, double angle) {
-  double s = sin(angle * 0.5);
-  q[0] = cos(angle * 0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+  double s, cs;
+  sincos(angle * 0.5, &s, &cs);
+  q[0] = cs; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
 __device__ __forceinline__ double dot6(const double* a, const double* b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
@@ -213,8 +230,9 @@ __device__ __forceinline__ void sphere_sphere(Con1& c, double margin, const doub
   double cd2 = dot3(dif, dif), mind = margin + r1 + r2;
   c.ok = 0;
   if (cd2 > mind * mind) return;
-  double len = sqrt(cd2);
-  if (len < MINVAL) { dif[0] = 0; dif[1] = 0; dif[2] = 1; } else { dif[0] /= len; dif[1] /= len; dif[2] /= len; }
+  double len;
+  if (cd2 < MINVAL * MINVAL) { len = sqrt(cd2); dif[0] = 0; dif[1] = 0; dif[2] = 1; }
+  else { double ri = fast_rsqrt(cd2); len = cd2 * ri; dif[0] *= ri; dif[1] *= ri; dif[2] *= ri; }
   c.dist = len - r1 - r2;
   for (int k = 0; k < 3; k++) { c.nrm[k] = dif[k]; c.pos[k] = p1[k] + dif[k] * (r1 + 0.5 * c.dist); }
   c.ok = 1;
@@ -306,6 +324,7 @@ struct Ctx {
   static constexpr int NV = NV_;                                  // compile-time nv (register-resident factorisation)
   static constexpr int EPL = (NV_ * (NV_ + 1) / 2 + WAVE - 1) / WAVE;
   static constexpr int PR = NV_ <= 28 ? 7 : NV_ <= 32 ? 10 : NV_ <= 36 ? 13 : NV_ <= 40 ? 17 : 21;  // rounds of 64 pairs
+  Layout L;             // LDS layout, copied from Params once per launch (wave-uniform -> SGPRs)
   LaneRec k;            // per-lane constants (registers)
   int prec[PR];
   float pbound[PR];
@@ -325,10 +344,10 @@ struct Ctx {
   int st_forward, st_newton, st_ncon, st_nefc, st_maxcon, st_maxefc, st_maxnewton, st_dropped;
 };
 
-#define S(off) (c.sm + c.P->L.off)
+#define S(off) (c.sm + c.L.off)
 // mass matrix element (i, j) of the block-diagonal storage; valid when i and j belong to the same agent tree
-#define MIDX(i, j) ((i) * c.P->L.mld + ((j) >= c.P->L.d1 ? (j) - c.P->L.d1 : (j)))
-#define SAME_TREE(i, j) (((i) >= c.P->L.d1) == ((j) >= c.P->L.d1))
+#define MIDX(i, j) ((i) * c.L.mld + ((j) >= c.L.d1 ? (j) - c.L.d1 : (j)))
+#define SAME_TREE(i, j) (((i) >= c.L.d1) == ((j) >= c.L.d1))
 #ifdef SUMO_PROFILE
 #define PROF(k) do { long long _t = clock64(); c.prof[k] += (unsigned long long)(_t - c.tprev); c.tprev = _t; } while (0)
 #else
@@ -407,7 +426,7 @@ __device__ __forceinline__ void position_velocity(C& c) {
   const LaneRec& K = c.k;
   const int lane = c.lane;
   const int nb = mdl.nbody, nv = mdl.nv;
-  for (int i = lane; i < c.P->L.msize; i += WAVE) S(M)[i] = 0.0;
+  for (int i = lane; i < c.L.msize; i += WAVE) S(M)[i] = 0.0;
   if (lane == 0) {
     S(xpos)[0] = S(xpos)[1] = S(xpos)[2] = 0;
     S(xquat)[0] = 1; S(xquat)[1] = S(xquat)[2] = S(xquat)[3] = 0;
@@ -564,13 +583,13 @@ __device__ __forceinline__ void mass_matrix(C& c) {
 // ---- collision ---------------------------------------------------------------------------------------------
 // "centre" index of a geom: its body id for agent geoms (one geom per moving body), nbody + w for world geom w.
 // Positions / axes of all centres live in the xipos / gaxis arrays (world entries are written once per launch).
-#define CTYPE(ci) (c.si[c.P->L.stat_i + (ci)])
-#define CBODY(ci) (c.si[c.P->L.stat_i + c.P->aux.nc + (ci)])
-#define CSIZE(ci) (c.sm + c.P->L.stat_d + 2 * (ci))
-#define CINVW(ci) (c.sm[c.P->L.stat_d + 2 * c.P->aux.nc + (ci)])
-#define WBOX(w) (c.sm + c.P->L.stat_d + 3 * c.P->aux.nc + 12 * (w))
-#define CHAINW(b) (c.si + c.P->L.stat_i + 2 * c.P->aux.nc + 2 * (b))
-#define CHLEN_AGENT(b) (c.si[c.P->L.stat_i + 2 * c.P->aux.nc + 2 * c.P->mdl.nbody + (b)])
+#define CTYPE(ci) (c.si[c.L.stat_i + (ci)])
+#define CBODY(ci) (c.si[c.L.stat_i + c.P->aux.nc + (ci)])
+#define CSIZE(ci) (c.sm + c.L.stat_d + 2 * (ci))
+#define CINVW(ci) (c.sm[c.L.stat_d + 2 * c.P->aux.nc + (ci)])
+#define WBOX(w) (c.sm + c.L.stat_d + 3 * c.P->aux.nc + 12 * (w))
+#define CHAINW(b) (c.si + c.L.stat_i + 2 * c.P->aux.nc + 2 * (b))
+#define CHLEN_AGENT(b) (c.si[c.L.stat_i + 2 * c.P->aux.nc + 2 * c.P->mdl.nbody + (b)])
 
 __device__ __forceinline__ void make_frame(double* f) {
   double n2 = sqrt(f[3] * f[3] + f[4] * f[4] + f[5] * f[5]);
@@ -587,8 +606,8 @@ __device__ __forceinline__ void make_frame(double* f) {
 template <class C>
 __device__ __forceinline__ void collision(C& c) {
   const int lane = c.lane, nb = c.P->mdl.nbody;
-  int* plist = c.si + c.P->L.plist;    // pair ids of broad-phase survivors (pair order preserved)
-  int* prlist = c.si + c.P->L.prlist;  // their packed centre records
+  int* plist = c.si + c.L.plist;    // pair ids of broad-phase survivors (pair order preserved)
+  int* prlist = c.si + c.L.prlist;  // their packed centre records
   int ncand = 0, ncon = 0, dropped = 0;
 #pragma unroll
   for (int r = 0; r < C::PR; r++) {
@@ -607,7 +626,7 @@ __device__ __forceinline__ void collision(C& c) {
     int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
     if (pass) { plist[pos] = lane + WAVE * r; prlist[pos] = rec; }
     ncand += __popcll(bal);
-    if (ncand + WAVE <= c.P->L.maxcand && r + 1 < C::PR) continue;
+    if (ncand + WAVE <= c.L.maxcand && r + 1 < C::PR) continue;
     SYNC();
     PROF(4);
     for (int k0 = 0; k0 < ncand; k0 += WAVE) {
@@ -706,14 +725,14 @@ __device__ __forceinline__ void collision(C& c) {
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         if (act[q]) {
-          if (slot < c.P->L.maxcon) {
+          if (slot < c.L.maxcon) {
             double* cd = S(cond) + 14 * slot;
             double fr[9] = {cs[q].nrm[0], cs[q].nrm[1], cs[q].nrm[2], 0, 0, 0, 0, 0, 0};
             make_frame(fr);
             cd[0] = cs[q].dist; cd[1] = cs[q].pos[0]; cd[2] = cs[q].pos[1]; cd[3] = cs[q].pos[2];
             for (int w = 0; w < 9; w++) cd[4 + w] = fr[w];
             cd[13] = 0;
-            int* cb = c.si + c.P->L.con_b + 4 * slot;
+            int* cb = c.si + c.L.con_b + 4 * slot;
             cb[0] = b1; cb[1] = b2; cb[2] = p; cb[3] = 0;
           }
           slot++;
@@ -725,7 +744,7 @@ __device__ __forceinline__ void collision(C& c) {
     SYNC();
     PROF(5);
   }
-  if (ncon > c.P->L.maxcon) { dropped = ncon - c.P->L.maxcon; ncon = c.P->L.maxcon; }
+  if (ncon > c.L.maxcon) { dropped = ncon - c.L.maxcon; ncon = c.L.maxcon; }
   c.ncon = ncon;
   c.ndropped = dropped;
   SYNC();
@@ -769,8 +788,8 @@ __device__ __forceinline__ void make_constraint(C& c) {
   const double timestep = MF(opt)[SUMO_OPT_TIMESTEP];
   const double def_solref[2] = {0.02, 1.0};
   const double def_solimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
-  int* lim_dof = c.si + c.P->L.lim_dof;
-  double* lim_sign = (double*)(c.si + c.P->L.lim_sign);
+  int* lim_dof = c.si + c.L.lim_dof;
+  double* lim_sign = (double*)(c.si + c.L.lim_sign);
   // joint limits (lower side first, then upper, joints in order); lane == joint id
   int nact = 0, act_lo = 0, act_hi = 0;
   double dlo = 0, dhi = 0;
@@ -783,11 +802,11 @@ __device__ __forceinline__ void make_constraint(C& c) {
     nact = act_lo + act_hi;
   }
   int nlim, base = wave_excl_scan(nact, lane, &nlim);
-  if (lane < nv) { (c.si + c.P->L.limrow)[lane] = 0; ((unsigned long long*)S(cmask))[lane] = 0ull; }
+  if (lane < nv) { (c.si + c.L.limrow)[lane] = 0; ((unsigned long long*)S(cmask))[lane] = 0ull; }
   SYNC();
   if (nact) {
     int dof = K.jt_dadr, r = base;
-    (c.si + c.P->L.limrow)[dof] = base | (nact << 8);
+    (c.si + c.L.limrow)[dof] = base | (nact << 8);
     double diag = K.jt_invw;
     if (act_lo) {
       double B, kt, R = row_params(timestep, def_solref, def_solimp, dlo, jm, diag, &B, &kt);
@@ -803,7 +822,7 @@ __device__ __forceinline__ void make_constraint(C& c) {
   // contact row parameters (same for the 4 pyramid edges of a contact)
   for (int ci = lane; ci < ncon; ci += WAVE) {
     const double* cd = S(cond) + 14 * ci;
-    const int* cb = c.si + c.P->L.con_b + 4 * ci;
+    const int* cb = c.si + c.L.con_b + 4 * ci;
     int p = cb[2];
     double mu = MF(pair_friction)[3 * p];
     double pm = MF(pair_margin)[p], pg = MF(pair_gap)[p];
@@ -820,13 +839,13 @@ __device__ __forceinline__ void make_constraint(C& c) {
   }
   PROF(6);
   // slot map init
-  unsigned char* slotof = c.sb + c.P->L.b_slotof;
+  unsigned char* slotof = c.sb + c.L.b_slotof;
   for (int i = lane; i < ncon * nv; i += WAVE) slotof[i] = 0xFF;
   SYNC();
   // compact contact Jacobians: 3 base rows (normal, t1, t2) x 16 slots (chain of body1 | chain of body2)
   for (int idx = lane; idx < ncon * 16; idx += WAVE) {
     int ci = idx >> 4, s = idx & 15, side = s >> 3, pos = s & 7;
-    const int* cb = c.si + c.P->L.con_b + 4 * ci;
+    const int* cb = c.si + c.L.con_b + 4 * ci;
     int body = side ? cb[1] : cb[0], other = side ? cb[0] : cb[1];
     int dof = -1, ag = 0;
     double j0 = 0, j1 = 0, j2 = 0;
@@ -854,7 +873,7 @@ __device__ __forceinline__ void make_constraint(C& c) {
       slotof[ci * nv + dof] = (unsigned char)s;
       atomicOr((unsigned long long*)S(cmask) + dof, 1ull << ci);
     }
-    ((signed char*)c.sb)[c.P->L.b_dofidx + idx] = (signed char)dof;
+    ((signed char*)c.sb)[c.L.b_dofidx + idx] = (signed char)dof;
     double* Jb = S(Jb) + 48 * ci;
     Jb[s] = j0; Jb[16 + s] = j1; Jb[32 + s] = j2;
   }
@@ -868,7 +887,7 @@ __device__ __forceinline__ void contact_Jx(C& c, const double* x) {
   for (int idx = c.lane; idx < 3 * c.ncon; idx += WAVE) {
     int ci = idx / 3, a = idx - 3 * ci;
     const double* Jb = S(Jb) + 48 * ci + 16 * a;
-    const signed char* di = (const signed char*)c.sb + c.P->L.b_dofidx + 16 * ci;
+    const signed char* di = (const signed char*)c.sb + c.L.b_dofidx + 16 * ci;
     double acc = 0;
     for (int s = 0; s < 16; s++) { int d = di[s]; if (d >= 0) acc += Jb[s] * x[d]; }
     S(cp)[idx] = acc;
@@ -878,10 +897,10 @@ __device__ __forceinline__ void contact_Jx(C& c, const double* x) {
 // value of row r of J*x given cp (after contact_Jx)
 template <class C>
 __device__ __forceinline__ double row_Jx(const C& c, int r, const double* x) {
-  if (r < c.nlim) return ((const double*)(c.si + c.P->L.lim_sign))[r] * x[(c.si + c.P->L.lim_dof)[r]];
+  if (r < c.nlim) return ((const double*)(c.si + c.L.lim_sign))[r] * x[(c.si + c.L.lim_dof)[r]];
   int q = r - c.nlim, ci = q >> 2, k = q & 3;
-  double mu = c.sm[c.P->L.cpar + ci];
-  const double* cp = c.sm + c.P->L.cp + 3 * ci;
+  double mu = c.sm[c.L.cpar + ci];
+  const double* cp = c.sm + c.L.cp + 3 * ci;
   return cp[0] + ((k & 1) ? -mu : mu) * cp[1 + (k >> 1)];
 }
 
@@ -890,20 +909,14 @@ template <class C>
 __device__ __forceinline__ double dense_Mx(const C& c, const double* x) {
   double acc = 0;
   if (c.lane < c.P->mdl.nv) {
-    const int d1 = c.P->L.d1, nv = c.P->mdl.nv;
+    const int d1 = c.L.d1, nv = c.P->mdl.nv;
     const int k0 = c.lane >= d1 ? d1 : 0, k1 = c.lane >= d1 ? nv : d1;
-    const double* row = c.sm + c.P->L.M + c.lane * c.P->L.mld;
+    const double* row = c.sm + c.L.M + c.lane * c.L.mld;
     for (int k = k0; k < k1; k++) acc += row[k - k0] * x[k];
   }
   return acc;
 }
 
-__device__ __forceinline__ double fast_rcp(double x) {  // v_rcp_f64 + two Newton steps (~1 ulp)
-  double r = __builtin_amdgcn_rcp(x);
-  r = r * (2.0 - x * r);
-  r = r * (2.0 - x * r);
-  return r;
-}
 // Solve A x = b for a symmetric positive definite A held in LDS (lower triangle, leading dim ld): lane i loads row i
 // into registers, the wave runs a right-looking LDL^T entirely with v_readlane broadcasts (no LDS traffic, no barriers;
 // fully unrolled so every register index is static), forward-substitutes, transposes L through LDS once (`T`, nv x ld)
@@ -911,7 +924,7 @@ __device__ __forceinline__ double fast_rcp(double x) {  // v_rcp_f64 + two Newto
 template <bool BLOCKDIAG, class C>
 __device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* T, double b, int* fail) {
   constexpr int NV = C::NV;
-  const int lane = c.lane, ld = c.P->L.ld;
+  const int lane = c.lane, ld = c.L.ld;
   const int li = lane < NV ? lane : NV - 1;
   double a[NV];
   if (BLOCKDIAG) {  // A is the block-diagonal mass matrix
@@ -926,16 +939,31 @@ __device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* 
   }
   double dinv = 0;
   int bad = 0;
+  if (BLOCKDIAG && c.L.d1 * 2 == NV) {
+    // two equal independent blocks: columns of block 0 never touch rows of block 1 (those entries are exact zeros)
 #pragma unroll
-  for (int j = 0; j < NV; j++) {
-    double ajj = readlane_f64(a[j], j);
-    if (ajj < MINVAL) bad = 1;
-    double r = fast_rcp(ajj);
-    double lij = a[j] * r;
+    for (int j = 0; j < NV; j++) {
+      double ajj = readlane_f64(a[j], j);
+      if (ajj < MINVAL) bad = 1;
+      double r = fast_rcp(ajj);
+      double lij = a[j] * r;
 #pragma unroll
-    for (int k = j + 1; k < NV; k++) a[k] -= lij * readlane_f64(a[j], k);  // lanes < k only touch unused entries
-    if (lane == j) dinv = r;
-    a[j] = lij;
+      for (int k = j + 1; k < (j < NV / 2 ? NV / 2 : NV); k++) a[k] -= lij * readlane_f64(a[j], k);
+      if (lane == j) dinv = r;
+      a[j] = lij;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      double ajj = readlane_f64(a[j], j);
+      if (ajj < MINVAL) bad = 1;
+      double r = fast_rcp(ajj);
+      double lij = a[j] * r;
+#pragma unroll
+      for (int k = j + 1; k < NV; k++) a[k] -= lij * readlane_f64(a[j], k);  // lanes < k only touch unused entries
+      if (lane == j) dinv = r;
+      a[j] = lij;
+    }
   }
   double y = b;
 #pragma unroll
@@ -975,7 +1003,7 @@ template <class C>
 __device__ __forceinline__ void newton_solve(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const Aux& aux = c.P->aux;
-  const int lane = c.lane, nv = mdl.nv, ld = c.P->L.ld, nefc = c.nefc, ncon = c.ncon, nlim = c.nlim;
+  const int lane = c.lane, nv = mdl.nv, ld = c.L.ld, nefc = c.nefc, ncon = c.ncon, nlim = c.nlim;
   const double tol = MF(opt)[SUMO_OPT_TOLERANCE];
   const int maxiter = (int)MF(opt)[SUMO_OPT_ITERATIONS];
   const double scale = 1.0 / (MF(opt)[SUMO_OPT_MEANINERTIA] * (nv > 1 ? nv : 1));
@@ -985,7 +1013,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
     SYNC();
     return;
   }
-  const unsigned char* slotof = c.sb + c.P->L.b_slotof;
+  const unsigned char* slotof = c.sb + c.L.b_slotof;
   // ---- warm start: better of qacc_warmstart (or, in warm_mode 1, the previous RK stage's qacc still held in x) and
   // qacc_smooth
   if (!c.use_prev && lane < nv) x[lane] = S(warm)[lane];
@@ -1042,8 +1070,8 @@ __device__ __forceinline__ void newton_solve(C& c) {
     double g = 0;
     if (lane < nv) {
       double qc = 0, dl = 0;
-      const double* lim_sign = (const double*)(c.si + c.P->L.lim_sign);
-      const int lr = (c.si + c.P->L.limrow)[lane];
+      const double* lim_sign = (const double*)(c.si + c.L.lim_sign);
+      const int lr = (c.si + c.L.limrow)[lane];
       for (int q = 0; q < (lr >> 8); q++) {
         int r = (lr & 0xFF) + q;
         double j = S(jar)[r];
@@ -1217,7 +1245,7 @@ __device__ __forceinline__ void mj_steps(C& c, int nsteps) {
   const double h = MF(opt)[SUMO_OPT_TIMESTEP];
   for (int sub = 0; sub < 4 * nsteps; sub++) {
     const int stage = sub & 3;
-    c.use_prev = (c.P->L.warm_mode == 1 && stage != 0) ? 1 : 0;
+    c.use_prev = (c.L.warm_mode == 1 && stage != 0) ? 1 : 0;
     forward(c);
     if (stage == 0) {
       if (lane < nq) S(x0)[lane] = S(qpos)[lane];
@@ -1336,6 +1364,7 @@ __device__ __forceinline__ float sumsq_f32(const float* a, int n) {  // numpy fl
 template <class C>
 __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.P = P;
+  c.L = P->L;
   c.sm = smem;
   c.si = (int*)(smem + P->L.i_base);
   c.sb = (unsigned char*)(smem + P->L.i_base);
@@ -1403,7 +1432,7 @@ __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
 extern __shared__ double smem_dyn[];
 
 template <int NV>
-__global__ void __launch_bounds__(WAVE) sumo_step_kernel(const Params* P, StepArgs a) {
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1))) sumo_step_kernel(const Params* P, StepArgs a) {
   Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
@@ -1507,7 +1536,7 @@ __global__ void __launch_bounds__(WAVE) sumo_reset_kernel(const Params* P, StepA
 }
 
 template <int NV>
-__global__ void __launch_bounds__(WAVE) sumo_forward_kernel(const Params* P, StepArgs a) {
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1))) sumo_forward_kernel(const Params* P, StepArgs a) {
   Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
