@@ -171,6 +171,13 @@ def main():
         total_steps = N * world * args.steps
         value = total_steps / dt_max
         B = algorithmic_bytes_per_env_step(model)
+        traffic = None
+        try:   # PMC traffic is collected offline with rocprofv3 (profiles/README.md); reported only for the profiled config
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pj["env_id"] == args.env_id and pj["envs"] == N:
+                traffic = pj["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         achieved = B * N / (kern_ms * 1e-3) / 1e9
         nfwd = max(1.0, st1["forward"] - st0["forward"])
         out = {
@@ -187,7 +194,7 @@ def main():
                        "mean_newton_iters_per_forward": (st1["newton"] - st0["newton"]) / nfwd,
                        "lds_bytes_per_env": env.engine.lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "sumo_step_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": B,
                          "note": "latency/ALU-bound physics: ~20 forward-dynamics solves per 2.4 KB of state traffic"},
         }
