@@ -335,7 +335,7 @@ struct Ctx {
   unsigned char* sb;  // LDS byte region (slotof)
   int lane;
   // per-forward scalars (wave-uniform)
-  int ncon, nlim, nefc, ndropped, use_prev;
+  int ncon, nlim, nefc, ndropped, use_prev, hblk;  // hblk: no contact couples the two agents -> H is block diagonal
 #ifdef SUMO_PROFILE
   long long tprev;
   unsigned long long prof[20];
@@ -751,6 +751,10 @@ __device__ __forceinline__ void collision(C& c) {
 }
 
 // ---- constraint rows -----------------------------------------------------------------------------------------
+__device__ __noinline__ double impedance_general_pow(double xx, double mid, double power) {  // rare: power not in {1, 2}
+  if (xx <= mid) return pow(xx, power) / pow(mid, power - 1);
+  return 1 - pow(1 - xx, power) / pow(1 - mid, power - 1);
+}
 __device__ __forceinline__ double impedance(const double* solimp, double x) {
   double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
   dmin = fmin(fmax(dmin, 0.0001), 0.9999);
@@ -762,8 +766,8 @@ __device__ __forceinline__ double impedance(const double* solimp, double x) {
   if (xx >= 1) return dmax;
   if (xx <= 0) return dmin;
   if (power == 1) y = xx;
-  else if (xx <= mid) y = pow(xx, power) / pow(mid, power - 1);
-  else y = 1 - pow(1 - xx, power) / pow(1 - mid, power - 1);
+  else if (power == 2) y = xx <= mid ? xx * xx / mid : 1 - (1 - xx) * (1 - xx) / (1 - mid);  // MuJoCo default solimp
+  else y = impedance_general_pow(xx, mid, power);
   return dmin + y * (dmax - dmin);
 }
 // returns R; writes B and K*imp*(pos-margin)
@@ -819,6 +823,14 @@ __device__ __forceinline__ void make_constraint(C& c) {
   }
   c.nlim = nlim;
   c.nefc = nlim + 4 * ncon;
+  {
+    int cross = 0;
+    for (int ci = lane; ci < ncon; ci += WAVE) {
+      const int* cb = c.si + c.L.con_b + 4 * ci;
+      if (cb[0] != 0 && cb[1] != 0 && (CHLEN_AGENT(cb[0]) >> 8) != (CHLEN_AGENT(cb[1]) >> 8)) cross = 1;
+    }
+    c.hblk = __ballot(cross) == 0ull;
+  }
   // contact row parameters (same for the 4 pyramid edges of a contact)
   for (int ci = lane; ci < ncon; ci += WAVE) {
     const double* cd = S(cond) + 14 * ci;
@@ -922,7 +934,7 @@ __device__ __forceinline__ double dense_Mx(const C& c, const double* x) {
 // fully unrolled so every register index is static), forward-substitutes, transposes L through LDS once (`T`, nv x ld)
 // and back-substitutes.  Lane i holds b_i on entry and returns x_i.  *fail is wave-uniform.
 template <bool BLOCKDIAG, class C>
-__device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* T, double b, int* fail) {
+__device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* T, double b, int* fail, int blk) {
   constexpr int NV = C::NV;
   const int lane = c.lane, ld = c.L.ld;
   const int li = lane < NV ? lane : NV - 1;
@@ -939,7 +951,7 @@ __device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* 
   }
   double dinv = 0;
   int bad = 0;
-  if (BLOCKDIAG && c.L.d1 * 2 == NV) {
+  if (blk && c.L.d1 * 2 == NV) {  // matrix is block diagonal (mass matrix; Hessian without agent-agent contacts)
     // two equal independent blocks: columns of block 0 never touch rows of block 1 (those entries are exact zeros)
 #pragma unroll
     for (int j = 0; j < NV; j++) {
@@ -1131,7 +1143,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
     SYNC();
     PROF(13);
     int hfail;
-    double sr = -ldl_solve_rows<false>(c, S(H), S(H), lane < nv ? S(grad)[lane] : 0.0, &hfail);
+    double sr = -ldl_solve_rows<false>(c, S(H), S(H), lane < nv ? S(grad)[lane] : 0.0, &hfail, c.hblk);
     if (hfail) break;
     if (lane < nv) S(search)[lane] = sr;
     SYNC();
@@ -1201,7 +1213,7 @@ __device__ __forceinline__ void forward(C& c) {
   SYNC();
   // qacc_smooth = M^-1 qfrc_smooth
   int mfail;
-  double as = ldl_solve_rows<true>(c, S(M), S(H), lane < nv ? S(qsm)[lane] : 0.0, &mfail);
+  double as = ldl_solve_rows<true>(c, S(M), S(H), lane < nv ? S(qsm)[lane] : 0.0, &mfail, 1);
   if (mfail) as = 0.0;
   if (lane < nv) S(asmo)[lane] = as;
   SYNC();
