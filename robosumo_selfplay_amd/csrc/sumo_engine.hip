@@ -1151,30 +1151,44 @@ __device__ __forceinline__ void newton_solve(C& c) {
     // ---- exact line search
     double Mv = dense_Mx(c, S(search));
     contact_Jx(c, S(search));
-    for (int r = lane; r < nefc; r += WAVE) S(Jv)[r] = row_Jx(c, r, S(search));
+    // each lane keeps its rows (r = lane + 64 q) of jar, Jv, D in registers for the whole search
+    constexpr int RPL = C::NV <= 28 ? 2 : 4;  // ceil(maxefc / 64): 128 rows (Ant scenes), <= 256 otherwise
+    double rj[RPL], rjv[RPL], rD[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      int r = lane + WAVE * q;
+      bool ok = r < nefc;
+      rjv[q] = ok ? row_Jx(c, r, S(search)) : 0.0;
+      rj[q] = ok ? S(jar)[r] : 1.0;      // inactive rows: jar > 0 and Jv = 0 never contribute
+      rD[q] = ok ? S(D)[r] : 0.0;
+    }
     double g1 = wave_sum(lane < nv ? sr * (Ma - S(qsm)[lane]) : 0.0);
     double g2 = wave_sum(lane < nv ? sr * Mv : 0.0);
-    SYNC();
     double alpha = 0, lo = 0, hi = -1, d0 = 0;
     for (int ls = 0; ls < 50; ls++) {
       double f1 = 0, f2 = 0;
-      for (int r = lane; r < nefc; r += WAVE) {
-        double jv = S(Jv)[r], j = S(jar)[r] + alpha * jv;
-        if (j < 0) { double Dr = S(D)[r]; f1 += Dr * j * jv; f2 += Dr * jv * jv; }
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        double j = rj[q] + alpha * rjv[q];
+        if (j < 0) { f1 += rD[q] * j * rjv[q]; f2 += rD[q] * rjv[q] * rjv[q]; }
       }
       f1 = wave_sum(f1) + (g1 + alpha * g2);
       f2 = wave_sum(f2) + g2;
       if (ls == 0) d0 = fabs(f1);
       if (fabs(f1) <= 1e-10 * d0) break;
       if (f1 < 0) lo = alpha; else hi = alpha;
-      double an = alpha - f1 / f2;
+      double an = alpha - f1 * fast_rcp(f2);
       if (an <= lo || (hi >= 0 && an >= hi)) an = hi >= 0 ? 0.5 * (lo + hi) : 2 * (alpha > 0 ? alpha : 1.0);
       alpha = an;
     }
     PROF(15);
     if (alpha == 0) break;
     if (lane < nv) { xi += alpha * sr; x[lane] = xi; Ma += alpha * Mv; }
-    for (int r = lane; r < nefc; r += WAVE) S(jar)[r] += alpha * S(Jv)[r];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      int r = lane + WAVE * q;
+      if (r < nefc) S(jar)[r] = rj[q] + alpha * rjv[q];
+    }
     SYNC();
     double oldcost = cost;
     cost = solver_cost(c, Ma, xi);
@@ -1872,6 +1886,7 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
   rc = build_aux(E, ai, af, pic);
   if (rc != 0) { delete E; return rc; }
   build_layout(E);
+  if (E->L.maxefc > WAVE * (E->hm.nv <= 28 ? 2 : 4)) { int me = E->L.maxefc; delete E; FAIL(-24, "maxefc %d exceeds the rows a lane keeps in registers", me); }
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   if ((size_t)E->L.total_bytes > prop.sharedMemPerBlock && (size_t)E->L.total_bytes > 160 * 1024) {
