@@ -79,8 +79,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("BENCH_BACKEND", "nccl")      # "nccl" is RCCL; "gloo" only to rehearse N>1 on a 1-GPU box
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(1, ndev)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

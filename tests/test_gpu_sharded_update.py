@@ -1,0 +1,78 @@
+"""§8(e) on one GPU: two ranks (gloo collectives over CUDA tensors, both on cuda:0) each train on half of a batch; the
+resulting parameters must be identical on both ranks and match a single-process update on the whole batch (pattern:
+reference baselines/baselines/ppo2/test_microbatches.py:12-32, whose tolerance is atol 3e-3; here 2e-5)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = pytest.mark.gpu
+
+OB, AC, N = 121, 8, 2048
+
+
+def _batch():
+    rng = np.random.RandomState(7)
+    obs = rng.normal(0, 1, (N, OB)).astype(np.float32)
+    act = rng.normal(0, 1, (N, AC)).astype(np.float32)
+    ret = rng.normal(0, 2, N).astype(np.float32)
+    val = rng.normal(0, 2, N).astype(np.float32)
+    old = rng.normal(11, 1, N).astype(np.float32)
+    return obs, act, ret, val, old
+
+
+def _train(comm, lo, hi, steps=3):
+    import torch
+    from robosumo_selfplay_amd import dist as sdist, model as model_mod, policies
+    np.random.seed(3)
+    spec = policies.PolicySpec(OB, AC, value_network="copy", activation="relu")
+    m = model_mod.PPOModel(policy=spec, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, comm=comm)
+    sdist.broadcast_params(m.params, comm)
+    obs, act, ret, val, old = (torch.as_tensor(x[lo:hi]).cuda() for x in _batch())
+    w = torch.ones(hi - lo, dtype=torch.float32, device="cuda")
+    stats = None
+    for _ in range(steps):
+        stats = m.train_indexed(1e-3, 0.2, obs, ret, act, val, old, w, None, hi - lo)
+    sdist.assert_synced(m.params, comm)
+    return m.params.cpu().numpy(), np.array(stats[:5], dtype=np.float64)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = N // world
+    p, st = _train(dist.group.WORLD, rank * per, (rank + 1) * per)
+    q.put((rank, p, st))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_two_shards_match_single_process():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, p, st = q.get(timeout=300)
+        res[r] = (p, st)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref_p, ref_st = _train(None, 0, N)
+    assert np.array_equal(res[0][0], res[1][0])                      # ranks stay bit-identical
+    assert np.allclose(res[0][0], ref_p, rtol=0, atol=2e-5), np.abs(res[0][0] - ref_p).max()
+    assert np.allclose(res[0][1], ref_st, rtol=1e-3, atol=1e-5)      # loss statistics are global means
+    assert np.allclose(res[1][1], ref_st, rtol=1e-3, atol=1e-5)
