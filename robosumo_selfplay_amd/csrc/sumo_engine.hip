@@ -893,16 +893,21 @@ __device__ __forceinline__ void make_constraint(C& c) {
   PROF(7);
 }
 
-// cp[3*c + a] = sum_s Jb[c][a][s] * x[dof(c,s)]
+// cp[3*c + a] = sum_s Jb[c][a][s] * x[dof(c,s)].  Branch-free and fully unrolled so all 16 slot loads are in flight at
+// once: Jb is exactly 0 in unused slots, so those may read any x.
 template <class C>
 __device__ __forceinline__ void contact_Jx(C& c, const double* x) {
   for (int idx = c.lane; idx < 3 * c.ncon; idx += WAVE) {
     int ci = idx / 3, a = idx - 3 * ci;
     const double* Jb = S(Jb) + 48 * ci + 16 * a;
     const signed char* di = (const signed char*)c.sb + c.L.b_dofidx + 16 * ci;
-    double acc = 0;
-    for (int s = 0; s < 16; s++) { int d = di[s]; if (d >= 0) acc += Jb[s] * x[d]; }
-    S(cp)[idx] = acc;
+    double xv[16], jv[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) { int d = di[s]; xv[s] = x[d < 0 ? 0 : d]; jv[s] = Jb[s]; }
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int s = 0; s < 16; s += 4) { a0 += jv[s] * xv[s]; a1 += jv[s + 1] * xv[s + 1]; a2 += jv[s + 2] * xv[s + 2]; a3 += jv[s + 3] * xv[s + 3]; }
+    S(cp)[idx] = (a0 + a1) + (a2 + a3);
   }
   SYNC();
 }
@@ -919,8 +924,17 @@ __device__ __forceinline__ double row_Jx(const C& c, int r, const double* x) {
 // y_i = sum_k M[i][k] x[k]   (x in LDS); M is block diagonal, so only the lane's own tree contributes
 template <class C>
 __device__ __forceinline__ double dense_Mx(const C& c, const double* x) {
+  constexpr int NV = C::NV;
   double acc = 0;
-  if (c.lane < c.P->mdl.nv) {
+  if (c.L.d1 * 2 == NV) {  // two equal trees: fixed trip count, all loads issued up front
+    const int li = c.lane < NV ? c.lane : 0;
+    const int k0 = li >= NV / 2 ? NV / 2 : 0;
+    const double* row = c.sm + c.L.M + li * c.L.mld;
+    double a0 = 0, a1 = 0;
+#pragma unroll
+    for (int k = 0; k < NV / 2; k += 2) { a0 += row[k] * x[k0 + k]; a1 += row[k + 1] * x[k0 + k + 1]; }
+    acc = c.lane < NV ? a0 + a1 : 0.0;
+  } else if (c.lane < c.P->mdl.nv) {
     const int d1 = c.L.d1, nv = c.P->mdl.nv;
     const int k0 = c.lane >= d1 ? d1 : 0, k1 = c.lane >= d1 ? nv : d1;
     const double* row = c.sm + c.L.M + c.lane * c.L.mld;
