@@ -156,7 +156,7 @@ def main():
             inds = torch.from_numpy(np.random.permutation(nb).astype(np.int32)).to(dev)
             for start in range(0, nb, nb // nmb):
                 mb = inds[start:start + nb // nmb]
-                learner.train_indexed(hp["lr"], hp["cliprange"], obs_b, ret_b, act_b, val_b, nlp_b, wts, mb, int(mb.numel()))
+                learner.train_indexed(hp["lr"], hp["cliprange"], obs_b, ret_b, act_b, val_b, nlp_b, wts, mb, int(mb.numel()), sync=False)
         barrier()
         t_upd = time.perf_counter() - tu
         tt = torch.tensor([t_upd, t_roll], dtype=torch.float64, device=dev)

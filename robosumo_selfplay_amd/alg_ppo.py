@@ -166,15 +166,20 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
             inds = torch.from_numpy(np.random.permutation(nsamp).astype(np.int32)).to(dev)    # np.random.shuffle (:375)
             for ii, start in enumerate(range(0, nsamp, nbatch_train)):
                 mb = inds[start:start + nbatch_train]
-                out = model.train_indexed(lrnow, cliprangenow, b_obs, b_ret, b_act, b_val, b_nlp, weights, mb, int(mb.numel()))
-                mblossvals.append(out[:5])
+                # statistics stay on the device unless the KL early stop needs them now (alg_ppo.py:389-398)
+                out = model.train_indexed(lrnow, cliprangenow, b_obs, b_ret, b_act, b_val, b_nlp, weights, mb, int(mb.numel()),
+                                          sync=kl_threshold is not None)
+                mblossvals.append(out[:5] if kl_threshold is not None else out)
                 if kl_threshold is not None and out[3] > kl_threshold * 1.5:
                     early_stop, stop_info = True, [epoch, ii]
                     break
             if early_stop:
                 break
         history["early_stop_info"].append(stop_info)
-        lossvals = np.mean(np.array(mblossvals, dtype=np.float64), axis=0)
+        if kl_threshold is None:
+            lossvals = torch.stack(mblossvals).mean(dim=0).cpu().numpy().astype(np.float64)
+        else:
+            lossvals = np.mean(np.array(mblossvals, dtype=np.float64), axis=0)
         history["lossvals"].append(lossvals)
         history["ppo_clip_frac"].append(lossvals[-1])
         history["approxkl"].append(lossvals[-2])

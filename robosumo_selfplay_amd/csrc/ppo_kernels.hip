@@ -215,7 +215,11 @@ extern "C" int ppo_forward(const float* params, const float* obs, int n, int obs
   a.L = make_layout(ob_dim, ac_dim);
   size_t lds = (size_t)4 * (16 * a.XS + 2 * 16 * HS) * sizeof(float);
   int tiles = (n + 15) / 16;
-  if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ppo_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static thread_local size_t lds_set = 0;   // raise the dynamic-LDS limit once (per thread / size), not on every launch
+  if (lds > 64 * 1024 && lds > lds_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)ppo_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
   hipLaunchKernelGGL(ppo_forward_kernel, dim3((tiles + 3) / 4), dim3(256), lds, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -607,7 +611,11 @@ extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, i
   // the slabs are only partially written by each net (its own ranges); the reduce reads only those ranges
 #define LAUNCH(KTV)                                                                                                     \
   do {                                                                                                                  \
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ppo_grad_kernel<KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    static thread_local size_t lds_set_##KTV = 0;                                                                       \
+    if (lds > 64 * 1024 && lds > lds_set_##KTV) {                                                                       \
+      HIPCHK(hipFuncSetAttribute((const void*)ppo_grad_kernel<KTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      lds_set_##KTV = lds;                                                                                              \
+    }                                                                                                                   \
     hipLaunchKernelGGL(ppo_grad_kernel<KTV>, dim3(nblocks, 2), dim3(256), lds, s, a);                                  \
   } while (0)
   if (KT <= 8) LAUNCH(8);

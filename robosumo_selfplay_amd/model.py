@@ -89,8 +89,10 @@ class PPOModel(object):
             return [np.float32(s) for s in stats] + [out[5].cpu().numpy(), None]
         return list(stats) + [out[5], None]
 
-    def train_indexed(self, lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n):
-        """One optimiser step on rows ``idx`` (int32 CUDA tensor or None) of device-resident batch arrays."""
+    def train_indexed(self, lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n, sync=True):
+        """One optimiser step on rows ``idx`` (int32 CUDA tensor or None) of device-resident batch arrays.
+        ``sync=False`` skips the host read-back of the loss statistics (returns a device tensor
+        [pg, vf, entropy, approxkl, clipfrac] instead) so consecutive minibatch steps queue without host stalls."""
         if not self.trainable:
             raise RuntimeError("model built with trainable=False")
         t = self._t
@@ -128,6 +130,9 @@ class PPOModel(object):
                                      self.t, float(lr), 0.9, 0.999, 1e-5,
                                      float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0,
                                      self.stats.data_ptr(), st))
+        if not sync:
+            st = self.stats
+            return t.stack([st[0] / st[6], st[1] / st[6], entropy_t, st[3] / st[6], st[4] / st[6]])
         s = self.stats.cpu().numpy()
         cnt = s[6]
         entropy = float(entropy_t.item())
