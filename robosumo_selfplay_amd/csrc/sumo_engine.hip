@@ -348,6 +348,7 @@ struct Ctx {
 // mass matrix element (i, j) of the block-diagonal storage; valid when i and j belong to the same agent tree
 #define MIDX(i, j) ((i) * c.L.mld + ((j) >= c.L.d1 ? (j) - c.L.d1 : (j)))
 #define SAME_TREE(i, j) (((i) >= c.L.d1) == ((j) >= c.L.d1))
+#define HP(i, k) ((i) * ((i) + 1) / 2 + (k))  /* packed lower-triangular index, i >= k */
 #ifdef SUMO_PROFILE
 #define PROF(k) do { long long _t = clock64(); c.prof[k] += (unsigned long long)(_t - c.tprev); c.tprev = _t; } while (0)
 #else
@@ -426,7 +427,6 @@ __device__ __forceinline__ void position_velocity(C& c) {
   const LaneRec& K = c.k;
   const int lane = c.lane;
   const int nb = mdl.nbody, nv = mdl.nv;
-  for (int i = lane; i < c.L.msize; i += WAVE) S(M)[i] = 0.0;
   if (lane == 0) {
     S(xpos)[0] = S(xpos)[1] = S(xpos)[2] = 0;
     S(xquat)[0] = 1; S(xquat)[1] = S(xquat)[2] = S(xquat)[3] = 0;
@@ -565,7 +565,9 @@ template <class C>
 __device__ __forceinline__ void mass_matrix(C& c) {
   const LaneRec& K = c.k;
   const int lane = c.lane, nv = c.P->mdl.nv;
-  gather_up(c, S(cinert), 10);  // cinert -> composite rigid body inertia, in place
+  // the contact records (dead by now) share the mass matrix's storage: clear it only here
+  for (int i = lane; i < c.L.msize; i += WAVE) S(M)[i] = 0.0;
+  gather_up(c, S(cinert), 10);  // cinert -> composite rigid body inertia, in place (ends with a SYNC)
   if (lane < nv) {
     const int i = lane;
     double buf[6];
@@ -950,7 +952,7 @@ __device__ __forceinline__ double dense_Mx(const C& c, const double* x) {
 template <bool BLOCKDIAG, class C>
 __device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* T, double b, int* fail, int blk) {
   constexpr int NV = C::NV;
-  const int lane = c.lane, ld = c.L.ld;
+  const int lane = c.lane;
   const int li = lane < NV ? lane : NV - 1;
   double a[NV];
   if (BLOCKDIAG) {  // A is the block-diagonal mass matrix
@@ -959,9 +961,9 @@ __device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* 
       int kk = k <= li ? k : li;
       a[k] = SAME_TREE(li, kk) ? A[MIDX(li, kk)] : 0.0;
     }
-  } else {
+  } else {  // A is the packed lower triangle (Hessian)
 #pragma unroll
-    for (int k = 0; k < NV; k++) a[k] = A[li * ld + (k <= li ? k : li)];
+    for (int k = 0; k < NV; k++) a[k] = A[HP(li, (k <= li ? k : li))];
   }
   double dinv = 0;
   int bad = 0;
@@ -998,13 +1000,17 @@ __device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* 
     if (lane > k) y -= a[k] * yk;
   }
   y *= dinv;
+  // write L back into the packed triangle (row `lane`), then every lane reads its COLUMN from there (back substitution)
+  {
+    const int rbase = HP(li, 0);
 #pragma unroll
-  for (int k = 0; k < NV - 1; k++)
-    if (lane > k && lane < NV) T[k * ld + lane] = a[k];  // T[i][k] = L[k][i]
+    for (int k = 0; k < NV - 1; k++)
+      if (lane > k && lane < NV) T[rbase + k] = a[k];
+  }
   SYNC();
   double t[NV];
 #pragma unroll
-  for (int k = 1; k < NV; k++) t[k] = T[li * ld + k];
+  for (int k = 1; k < NV; k++) t[k] = T[HP(k, li)];   // L[k][lane]; entries with k <= lane are never used
 #pragma unroll
   for (int k = NV - 1; k > 0; k--) {
     double xk = readlane_f64(y, k);
@@ -1151,7 +1157,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
 #pragma unroll
       for (int m = 0; m < C::EPL; m++) {
         unsigned e = c.ent[m];
-        if (e != 0xFFFFu) S(H)[(e >> 8) * ld + (e & 0xFF)] = hreg[m];
+        if (e != 0xFFFFu) S(H)[HP((int)(e >> 8), (int)(e & 0xFF))] = hreg[m];
       }
     }
     SYNC();
@@ -1847,15 +1853,14 @@ static void build_layout(sumo_engine* E) {
   auto take = [&](int n) { int r = o; o += n; return r; };
   L.qpos = take(nq); L.qvel = take(nv); L.warm = take(nv); L.ctrl = take(nu);
   L.x0 = take(nq + nv); L.accv = take(nv); L.acca = take(nv); L.tmpv = take(nv);
-  // kinematic scratch (dead once the mass matrix is built) -- H aliases its start
-  int kin0 = o;
+  // kinematic data needed until the mass matrix is built (com, cinert -> crb, cdof); the packed Hessian aliases it
   const int nc = E->aux.nc;
-  L.xpos = take(3 * nb); L.xquat = take(4 * nb);
-  L.xanchor = take(3 * nj); L.xaxis = take(3 * nj); L.com = take(3 * m->nagent);
-  L.cinert = take(10 * nb); L.cdof = take(6 * nv); L.abuf = take(6 * nb); L.cfrc = take(6 * nb);
+  const int ntri = nv * (nv + 1) / 2;
+  int kin0 = o;
+  L.com = take(3 * m->nagent); L.cinert = take(10 * nb); L.cdof = take(6 * nv);
   L.H = kin0;
-  if (o - kin0 < nv * L.ld) o = kin0 + nv * L.ld;
-  // centre positions / axes: bodies (rewritten every forward) then world geoms (static) -- must survive H
+  if (o - kin0 < ntri) o = kin0 + ntri;
+  // centre positions / axes: bodies (rewritten every forward) then world geoms (static)
   L.xipos = take(3 * nc); L.gaxis = take(3 * nc);
   L.stat_d = take(E->aux.n_stat_d);
   {
@@ -1865,9 +1870,21 @@ static void build_layout(sumo_engine* E) {
     L.d1 = SUMO_I(m, agent_dofadr)[1];
     L.msize = (nv0 + nv1) * L.mld;
   }
-  L.M = take(L.msize); L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = take(nv);
+  L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = take(nv);
   L.search = take(nv); L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv);
-  L.cond = take(14 * L.maxcon); L.Jb = take(48 * L.maxcon); L.cpar = take(L.maxcon); L.cW = take(6 * L.maxcon);
+  // contact records live from the narrow phase to the Jacobian build only: they borrow the mass matrix's storage
+  if (L.msize < 14 * L.maxcon) L.msize = 14 * L.maxcon;
+  L.M = take(L.msize);
+  L.cond = L.M;
+  // body frames / joint anchors / RNE temporaries are dead before the contact Jacobians are written: same storage
+  {
+    int jb0 = o, need = 19 * nb + 6 * nj, jbsz = 48 * L.maxcon;
+    L.Jb = take(jbsz > need ? jbsz : need);
+    int q = jb0;
+    L.xpos = q; q += 3 * nb; L.xquat = q; q += 4 * nb; L.xanchor = q; q += 3 * nj; L.xaxis = q; q += 3 * nj;
+    L.abuf = q; q += 6 * nb; L.cfrc = q; q += 6 * nb;
+  }
+  L.cpar = take(L.maxcon); L.cW = take(6 * L.maxcon);
   L.cp = take(3 * L.maxcon);
   L.jar = take(L.maxefc); L.Jv = take(L.maxefc); L.D = take(L.maxefc); L.aref = take(L.maxefc);
   L.i_base = o;
