@@ -325,9 +325,9 @@ struct Ctx {
   static constexpr int EPL = (NV_ * (NV_ + 1) / 2 + WAVE - 1) / WAVE;
   static constexpr int PR = NV_ <= 28 ? 7 : NV_ <= 32 ? 10 : NV_ <= 36 ? 13 : NV_ <= 40 ? 17 : 21;  // rounds of 64 pairs
   Layout L;             // LDS layout, copied from Params once per launch (wave-uniform -> SGPRs)
-  LaneRec k;            // per-lane constants (registers)
-  int prec[PR];
-  float pbound[PR];
+  const LaneRec* kp;    // this lane's constant record (device memory, L1-resident); phases copy the fields they need
+  const int* prp;       // this lane's packed pair records / bounds: element r*64
+  const float* pbp;
   unsigned ent[EPL];  // lower-triangle entries assembled by this lane (i << 8 | k), entry t = lane + 64*m; 0xFFFF = none
   const Params* P;
   double* sm;    // LDS base (doubles)
@@ -345,6 +345,12 @@ struct Ctx {
 };
 
 #define S(off) (c.sm + c.L.off)
+// Per-lane constants are re-read at the start of each phase instead of being pinned in registers for the whole launch
+// (the optimisation barrier stops the compiler from hoisting the loads back to kernel entry): this keeps the kernel
+// within 256 registers, i.e. two waves per SIMD.
+template <class T>
+__device__ __forceinline__ const T* launder_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; }
+#define KCONSTS() const LaneRec K = *launder_ptr(c.kp)
 // mass matrix element (i, j) of the block-diagonal storage; valid when i and j belong to the same agent tree
 #define MIDX(i, j) ((i) * c.L.mld + ((j) >= c.L.d1 ? (j) - c.L.d1 : (j)))
 #define SAME_TREE(i, j) (((i) >= c.L.d1) == ((j) >= c.L.d1))
@@ -360,7 +366,7 @@ struct Ctx {
 
 template <class C>
 __device__ __forceinline__ void kin_own_body(C& c) {  // lane == body id
-  const LaneRec& K = c.k;
+  KCONSTS();
   const int b = c.lane, pid = K.b_parent;
   double* qpos = S(qpos);
   double xp[3], xq[4], R[9], v[3];
@@ -407,7 +413,7 @@ __device__ __forceinline__ void kin_own_body(C& c) {  // lane == body id
 // gather children into parents, level by level, for an array of `w` doubles per body (lane == body id)
 template <class C>
 __device__ __forceinline__ void gather_up(C& c, double* arr, int w) {
-  const LaneRec& K = c.k;
+  KCONSTS();
   const int b = c.lane;
   for (int lvl = c.P->aux.ndepth - 2; lvl >= 1; lvl--) {
     if (K.b_level == lvl) {
@@ -424,7 +430,6 @@ template <class C>
 __device__ __forceinline__ void position_velocity(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const Aux& aux = c.P->aux;
-  const LaneRec& K = c.k;
   const int lane = c.lane;
   const int nb = mdl.nbody, nv = mdl.nv;
   if (lane == 0) {
@@ -434,13 +439,17 @@ __device__ __forceinline__ void position_velocity(C& c) {
   }
   SYNC();
   PROF(0);
-  for (int lvl = 1; lvl < aux.ndepth; lvl++) {
-    if (K.b_level == lvl) kin_own_body(c);
-    SYNC();
+  {
+    const int my_level = launder_ptr(c.kp)->b_level;
+    for (int lvl = 1; lvl < aux.ndepth; lvl++) {
+      if (my_level == lvl) kin_own_body(c);
+      SYNC();
+    }
   }
   PROF(1);
   // subtree CoM of each agent's root
   {
+    KCONSTS();
     const bool isb = lane >= 1 && lane < nb;
     double px = 0, py = 0, pz = 0;
     if (isb) { px = K.b_mass * S(xipos)[3 * lane]; py = K.b_mass * S(xipos)[3 * lane + 1]; pz = K.b_mass * S(xipos)[3 * lane + 2]; }
@@ -456,6 +465,7 @@ __device__ __forceinline__ void position_velocity(C& c) {
   SYNC();
   // cinert per body, cdof per joint
   if (lane >= 1 && lane < nb) {
+    KCONSTS();
     const int b = lane, ag = K.b_agent;
     double qi[4], R[9], dif[3], T[9];
     mulquat(qi, S(xquat) + 4 * b, K.b_iquat);
@@ -477,6 +487,7 @@ __device__ __forceinline__ void position_velocity(C& c) {
     res[9] = ms;
   }
   if (lane < mdl.njnt) {
+    KCONSTS();
     const int j = lane, b = K.jt_body, da = K.jt_dadr, ag = K.jt_agent;
     double off[3];
     for (int k = 0; k < 3; k++) off[k] = S(com)[3 * ag + k] - S(xanchor)[3 * j + k];
@@ -506,6 +517,7 @@ __device__ __forceinline__ void position_velocity(C& c) {
   // body velocities along each body's dof chain; a_b = sum over the body's own dofs of cdof_dot * qvel
   double cvel[6] = {0, 0, 0, 0, 0, 0};
   if (lane >= 1 && lane < nb) {
+    KCONSTS();
     const int b = lane;
     double a[6] = {0, 0, 0, 0, 0, 0}, cd[6];
     const double* qvel = S(qvel);
@@ -543,6 +555,7 @@ __device__ __forceinline__ void position_velocity(C& c) {
     double* f = S(cfrc) + 6 * b;
     if (b == 0) { for (int q = 0; q < 6; q++) f[q] = 0; }
     else {
+      KCONSTS();
       const double* g = MF(opt) + SUMO_OPT_GRAVITY;
       double cacc[6] = {0, 0, 0, -g[0], -g[1], -g[2]}, t[6], t1[6];
       for (int p = 0; p < K.b_bchain_len; p++) {
@@ -557,13 +570,13 @@ __device__ __forceinline__ void position_velocity(C& c) {
   }
   SYNC();
   gather_up(c, S(cfrc), 6);
-  if (lane < nv) S(bias)[lane] = dot6(S(cdof) + 6 * lane, S(cfrc) + 6 * K.d_body);
+  if (lane < nv) S(bias)[lane] = dot6(S(cdof) + 6 * lane, S(cfrc) + 6 * launder_ptr(c.kp)->d_body);
   PROF(3);
 }
 
 template <class C>
 __device__ __forceinline__ void mass_matrix(C& c) {
-  const LaneRec& K = c.k;
+  KCONSTS();
   const int lane = c.lane, nv = c.P->mdl.nv;
   // the contact records (dead by now) share the mass matrix's storage: clear it only here
   for (int i = lane; i < c.L.msize; i += WAVE) S(M)[i] = 0.0;
@@ -611,15 +624,17 @@ __device__ __forceinline__ void collision(C& c) {
   int* plist = c.si + c.L.plist;    // pair ids of broad-phase survivors (pair order preserved)
   int* prlist = c.si + c.L.prlist;  // their packed centre records
   int ncand = 0, ncon = 0, dropped = 0;
+  const int* prp = launder_ptr(c.prp);
+  const float* pbp = launder_ptr(c.pbp);
 #pragma unroll
   for (int r = 0; r < C::PR; r++) {
-    const int rec = c.prec[r];
+    const int rec = prp[WAVE * r];
     int pass = 0;
     if (rec & (1 << 17)) {
       const int c1 = rec & 0xFF, c2 = (rec >> 8) & 0xFF;
       const double* p1 = S(xipos) + 3 * c1;
       const double* p2 = S(xipos) + 3 * c2;
-      const double bound = (double)c.pbound[r];
+      const double bound = (double)pbp[WAVE * r];
       double t[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
       if (rec & (1 << 16)) pass = !(dot3(t, S(gaxis) + 3 * c1) > bound);
       else pass = !(dot3(t, t) > bound * bound);
@@ -789,7 +804,7 @@ __device__ __forceinline__ double row_params(double timestep, const double* solr
 template <class C>
 __device__ __forceinline__ void make_constraint(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
-  const LaneRec& K = c.k;
+  KCONSTS();
   const int lane = c.lane, nv = mdl.nv, ncon = c.ncon;
   const double timestep = MF(opt)[SUMO_OPT_TIMESTEP];
   const double def_solref[2] = {0.02, 1.0};
@@ -1236,13 +1251,14 @@ __device__ __forceinline__ void forward(C& c) {
   mass_matrix(c);  // last user of the kinematic scratch; H may overwrite it from here on
   PROF(9);
   // smooth forces: passive (damping) - bias + actuation
-  if (lane < nv) S(qsm)[lane] = -c.k.d_damp * S(qvel)[lane] - S(bias)[lane];
+  KCONSTS();
+  if (lane < nv) S(qsm)[lane] = -K.d_damp * S(qvel)[lane] - S(bias)[lane];
   SYNC();
   if (lane < mdl.nu) {
     double u = S(ctrl)[lane];
-    if (u < c.k.a_lo) u = c.k.a_lo;
-    if (u > c.k.a_hi) u = c.k.a_hi;
-    S(qsm)[c.k.a_dof] += c.k.a_gear * u;  // one motor per dof in these scenes
+    if (u < K.a_lo) u = K.a_lo;
+    if (u > K.a_hi) u = K.a_hi;
+    S(qsm)[K.a_dof] += K.a_gear * u;  // one motor per dof in these scenes
   }
   SYNC();
   // qacc_smooth = M^-1 qfrc_smooth
@@ -1264,7 +1280,7 @@ __device__ __forceinline__ void forward(C& c) {
 // qpos '+'= h * vel  (vel in LDS), one lane per joint
 template <class C>
 __device__ __forceinline__ void integrate_pos(C& c, double* qpos, const double* vel, double h) {
-  const LaneRec& K = c.k;
+  KCONSTS();
   if (c.lane < c.P->mdl.njnt) {
     const int qa = K.jt_qadr, da = K.jt_dadr;
     if (K.jt_type == SUMO_JNT_FREE) {
@@ -1420,9 +1436,9 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
     int t = c.lane + WAVE * m;
     c.ent[m] = t < P->aux.ntri ? (unsigned)((P->aux.ai[P->aux.o_tri_i + t] << 8) | P->aux.ai[P->aux.o_tri_j + t]) : 0xFFFFu;
   }
-  c.k = P->lanes[c.lane];
-#pragma unroll
-  for (int r = 0; r < C::PR; r++) { c.prec[r] = P->pair_rec[c.lane + WAVE * r]; c.pbound[r] = P->pair_bound[c.lane + WAVE * r]; }
+  c.kp = P->lanes + c.lane;
+  c.prp = P->pair_rec + c.lane;
+  c.pbp = P->pair_bound + c.lane;
   // static tables -> LDS (once per launch); world centres into the tail of xipos / gaxis
   for (int i = c.lane; i < P->aux.n_stat_d; i += WAVE) smem[P->L.stat_d + i] = P->aux.af[P->aux.o_stat_d + i];
   for (int i = c.lane; i < P->aux.n_stat_i; i += WAVE) c.si[P->L.stat_i + i] = P->aux.ai[P->aux.o_stat_i + i];
@@ -1478,7 +1494,7 @@ __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
 extern __shared__ double smem_dyn[];
 
 template <int NV>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1))) sumo_step_kernel(const Params* P, StepArgs a) {
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) sumo_step_kernel(const Params* P, StepArgs a) {
   Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
@@ -1582,7 +1598,7 @@ __global__ void __launch_bounds__(WAVE) sumo_reset_kernel(const Params* P, StepA
 }
 
 template <int NV>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1))) sumo_forward_kernel(const Params* P, StepArgs a) {
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) sumo_forward_kernel(const Params* P, StepArgs a) {
   Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
