@@ -59,7 +59,8 @@ struct Layout {  // LDS offsets in doubles unless noted
   int H;                                                                           // aliases kin scratch
   int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim;
   int cmask;     // per dof: 64-bit mask of the contacts whose Jacobian touches the dof
-  int cond, Jb, cpar, cW, cp, jar, Jv, D, aref;
+  int cond, Jb, cpar, cW, cp, jar, D, aref;
+  int maxlim;    // capacity of limit rows (2 per hinge); D holds maxlim limit entries then one per contact
   int stat_d;    // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wpos[3*nworld] | waxis[3*nworld]
   int i_base;  // start of int region (in doubles)
   // int region offsets (in ints, relative to int base)
@@ -354,6 +355,8 @@ __device__ __forceinline__ const T* launder_ptr(const T* p) { asm volatile("" : 
 // mass matrix element (i, j) of the block-diagonal storage; valid when i and j belong to the same agent tree
 #define MIDX(i, j) ((i) * c.L.mld + ((j) >= c.L.d1 ? (j) - c.L.d1 : (j)))
 #define SAME_TREE(i, j) (((i) >= c.L.d1) == ((j) >= c.L.d1))
+// D of constraint row r: limit rows store their own, the four rows of a contact share one
+#define ROWD(r) ((r) < c.nlim ? S(D)[r] : S(D)[c.L.maxlim + (((r) - c.nlim) >> 2)])
 #define HP(i, k) ((i) * ((i) + 1) / 2 + (k))  /* packed lower-triangular index, i >= k */
 #ifdef SUMO_PROFILE
 #define PROF(k) do { long long _t = clock64(); c.prof[k] += (unsigned long long)(_t - c.tprev); c.tprev = _t; } while (0)
@@ -831,11 +834,11 @@ __device__ __forceinline__ void make_constraint(C& c) {
     double diag = K.jt_invw;
     if (act_lo) {
       double B, kt, R = row_params(timestep, def_solref, def_solimp, dlo, jm, diag, &B, &kt);
-      lim_dof[r] = dof; lim_sign[r] = 1.0; S(D)[r] = 1.0 / R; S(Jv)[r] = B; S(jar)[r] = kt; r++;
+      lim_dof[r] = dof; lim_sign[r] = 1.0; S(D)[r] = 1.0 / R; S(aref)[r] = B; S(jar)[r] = kt; r++;
     }
     if (act_hi) {
       double B, kt, R = row_params(timestep, def_solref, def_solimp, dhi, jm, diag, &B, &kt);
-      lim_dof[r] = dof; lim_sign[r] = -1.0; S(D)[r] = 1.0 / R; S(Jv)[r] = B; S(jar)[r] = kt; r++;
+      lim_dof[r] = dof; lim_sign[r] = -1.0; S(D)[r] = 1.0 / R; S(aref)[r] = B; S(jar)[r] = kt; r++;
     }
   }
   c.nlim = nlim;
@@ -864,7 +867,8 @@ __device__ __forceinline__ void make_constraint(C& c) {
     double Rpy = 2 * mu * mu * R;
     if (Rpy < MINVAL) Rpy = MINVAL;
     S(cpar)[ci] = mu;
-    for (int k = 0; k < 4; k++) { int r = nlim + 4 * ci + k; S(D)[r] = 1.0 / Rpy; S(Jv)[r] = B; S(jar)[r] = kt; }
+    S(D)[c.L.maxlim + ci] = 1.0 / Rpy;   // one D per contact (its four pyramid rows share it)
+    for (int k = 0; k < 4; k++) { int r = nlim + 4 * ci + k; S(aref)[r] = B; S(jar)[r] = kt; }
   }
   PROF(6);
   // slot map init
@@ -1042,7 +1046,7 @@ __device__ __forceinline__ double solver_cost(C& c, double Ma_i, double x_i) {
   const int lane = c.lane, nv = c.P->mdl.nv;
   double v = 0;
   if (lane < nv) v = 0.5 * (Ma_i - S(qsm)[lane]) * (x_i - S(asmo)[lane]);
-  for (int r = lane; r < c.nefc; r += WAVE) { double j = S(jar)[r]; if (j < 0) v += 0.5 * S(D)[r] * j * j; }
+  for (int r = lane; r < c.nefc; r += WAVE) { double j = S(jar)[r]; if (j < 0) v += 0.5 * ROWD(r) * j * j; }
   return wave_sum(v);
 }
 
@@ -1072,18 +1076,22 @@ __device__ __forceinline__ void newton_solve(C& c) {
   double xi = lane < nv ? x[lane] : 0.0;
   double cost_ws = solver_cost(c, Ma, xi);
   contact_Jx(c, S(asmo));
+  constexpr int RPLW = C::NV <= 28 ? 2 : 4;   // rows per lane (see the line search)
+  double jsm[RPLW];
   double csm = 0;
-  for (int r = lane; r < nefc; r += WAVE) {
-    double jv = row_Jx(c, r, S(asmo)) - S(aref)[r];
-    S(Jv)[r] = jv;
-    if (jv < 0) csm += 0.5 * S(D)[r] * jv * jv;
+#pragma unroll
+  for (int q = 0; q < RPLW; q++) {
+    int r = lane + WAVE * q;
+    double jv = r < nefc ? row_Jx(c, r, S(asmo)) - S(aref)[r] : 1.0;
+    jsm[q] = jv;
+    if (jv < 0) csm += 0.5 * ROWD(r) * jv * jv;
   }
   double cost_sm = wave_sum(csm);
-  SYNC();
   double cost = cost_ws;
   if (cost_ws > cost_sm) {
     if (lane < nv) { xi = S(asmo)[lane]; x[lane] = xi; }
-    for (int r = lane; r < nefc; r += WAVE) S(jar)[r] = S(Jv)[r];
+#pragma unroll
+    for (int q = 0; q < RPLW; q++) { int r = lane + WAVE * q; if (r < nefc) S(jar)[r] = jsm[q]; }
     SYNC();
     Ma = dense_Mx(c, x);
     cost = solver_cost(c, Ma, xi);
@@ -1097,7 +1105,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
       double mu = S(cpar)[ci], f[4], dact[4];
       for (int k = 0; k < 4; k++) {
         int r = nlim + 4 * ci + k;
-        double j = S(jar)[r], Dr = S(D)[r];
+        double j = S(jar)[r], Dr = S(D)[c.L.maxlim + ci];
         dact[k] = j < 0 ? Dr : 0.0;
         f[k] = j < 0 ? -Dr * j : 0.0;
       }
@@ -1195,7 +1203,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
       bool ok = r < nefc;
       rjv[q] = ok ? row_Jx(c, r, S(search)) : 0.0;
       rj[q] = ok ? S(jar)[r] : 1.0;      // inactive rows: jar > 0 and Jv = 0 never contribute
-      rD[q] = ok ? S(D)[r] : 0.0;
+      rD[q] = ok ? ROWD(r) : 0.0;
     }
     double g1 = wave_sum(lane < nv ? sr * (Ma - S(qsm)[lane]) : 0.0);
     double g2 = wave_sum(lane < nv ? sr * Mv : 0.0);
@@ -1245,7 +1253,7 @@ __device__ __forceinline__ void forward(C& c) {
   make_constraint(c);
   // efc_vel and aref (B and K*imp*(pos-margin) were parked in Jv / jar)
   contact_Jx(c, S(qvel));
-  for (int r = lane; r < c.nefc; r += WAVE) S(aref)[r] = -S(Jv)[r] * row_Jx(c, r, S(qvel)) - S(jar)[r];
+  for (int r = lane; r < c.nefc; r += WAVE) S(aref)[r] = -S(aref)[r] * row_Jx(c, r, S(qvel)) - S(jar)[r];  // B was parked in aref
   SYNC();
   PROF(8);
   mass_matrix(c);  // last user of the kinematic scratch; H may overwrite it from here on
@@ -1305,36 +1313,37 @@ __device__ __forceinline__ void mj_steps(C& c, int nsteps) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane, nq = mdl.nq, nv = mdl.nv;
   const double h = MF(opt)[SUMO_OPT_TIMESTEP];
+  double q0 = 0, v0 = 0, accv = 0, acca = 0;   // this lane's entry of the step's start state and of the RK4 accumulators
   for (int sub = 0; sub < 4 * nsteps; sub++) {
     const int stage = sub & 3;
     c.use_prev = (c.L.warm_mode == 1 && stage != 0) ? 1 : 0;
     forward(c);
     if (stage == 0) {
-      if (lane < nq) S(x0)[lane] = S(qpos)[lane];
+      if (lane < nq) q0 = S(qpos)[lane];
       if (lane < nv) {
-        S(x0)[nq + lane] = S(qvel)[lane];
-        S(accv)[lane] = 0.0 + (1.0 / 6.0) * S(qvel)[lane];
-        S(acca)[lane] = 0.0 + (1.0 / 6.0) * S(x)[lane];
+        v0 = S(qvel)[lane];
+        accv = 0.0 + (1.0 / 6.0) * S(qvel)[lane];
+        acca = 0.0 + (1.0 / 6.0) * S(x)[lane];
       }
     } else {
       const double Bi = stage == 3 ? 1.0 / 6.0 : 1.0 / 3.0;
-      if (lane < nv) { S(accv)[lane] += Bi * S(qvel)[lane]; S(acca)[lane] += Bi * S(x)[lane]; }
+      if (lane < nv) { accv += Bi * S(qvel)[lane]; acca += Bi * S(x)[lane]; }
     }
     SYNC();
     if (stage < 3) {
       const double Ai = stage == 2 ? 1.0 : 0.5;  // A[stage]
       double dv = 0;
       if (lane < nv) { S(tmpv)[lane] = Ai * S(qvel)[lane]; dv = Ai * S(x)[lane]; }
-      if (lane < nq) S(qpos)[lane] = S(x0)[lane];
+      if (lane < nq) S(qpos)[lane] = q0;
       SYNC();
       integrate_pos(c, S(qpos), S(tmpv), h);
-      if (lane < nv) S(qvel)[lane] = S(x0)[nq + lane] + h * dv;
+      if (lane < nv) S(qvel)[lane] = v0 + h * dv;
       SYNC();
     } else {
-      if (lane < nq) S(qpos)[lane] = S(x0)[lane];
-      if (lane < nv) { S(qvel)[lane] = S(x0)[nq + lane] + h * S(acca)[lane]; S(warm)[lane] = S(x)[lane]; }
+      if (lane < nq) S(qpos)[lane] = q0;
+      if (lane < nv) { S(qvel)[lane] = v0 + h * acca; S(warm)[lane] = S(x)[lane]; S(tmpv)[lane] = accv; }
       SYNC();
-      integrate_pos(c, S(qpos), S(accv), h);
+      integrate_pos(c, S(qpos), S(tmpv), h);
       SYNC();
     }
   }
@@ -1864,11 +1873,11 @@ static void build_layout(sumo_engine* E) {
   if (L.maxcon > 64) L.maxcon = 64;  // per-dof contact masks are 64 bits wide
   L.maxefc = 4 * L.maxcon + 2 * nhinge;
   { const char* wm = getenv("SUMO_WARM_MODE"); L.warm_mode = wm ? atoi(wm) : 0; }
-  L.maxcand = 96;  // queue of broad-phase survivors, drained by the narrow phase before it can overflow
+  L.maxcand = 64;  // queue of broad-phase survivors, drained by the narrow phase before it can overflow
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
   L.qpos = take(nq); L.qvel = take(nv); L.warm = take(nv); L.ctrl = take(nu);
-  L.x0 = take(nq + nv); L.accv = take(nv); L.acca = take(nv); L.tmpv = take(nv);
+  L.x0 = 0; L.accv = 0; L.acca = 0; L.tmpv = take(nv);
   // kinematic data needed until the mass matrix is built (com, cinert -> crb, cdof); the packed Hessian aliases it
   const int nc = E->aux.nc;
   const int ntri = nv * (nv + 1) / 2;
@@ -1902,7 +1911,8 @@ static void build_layout(sumo_engine* E) {
   }
   L.cpar = take(L.maxcon); L.cW = take(6 * L.maxcon);
   L.cp = take(3 * L.maxcon);
-  L.jar = take(L.maxefc); L.Jv = take(L.maxefc); L.D = take(L.maxefc); L.aref = take(L.maxefc);
+  L.maxlim = 2 * nhinge;
+  L.jar = take(L.maxefc); L.D = take(L.maxlim + L.maxcon); L.aref = take(L.maxefc);
   L.i_base = o;
   int io = 0;
   auto itake = [&](int n) { int r = io; io += n; return r; };
