@@ -25,6 +25,9 @@
 #include "../../include/sumo_model.h"
 
 #define WAVE 64
+#ifndef SUMO_WPE
+#define SUMO_WPE 2  /* waves per SIMD the register allocator targets: 2 -> at most 256 registers per lane */
+#endif
 #define MINVAL 1e-15
 #define MAXCHAIN 8   /* dofs on the path root -> body (free joint 6 + hip + ankle) */
 #define MAXBCHAIN 4  /* bodies on the path root -> body */
@@ -58,6 +61,7 @@ struct Layout {  // LDS offsets in doubles unless noted
   int xpos, xquat, xipos, gaxis, xanchor, xaxis, com, cinert, cdof, abuf, cfrc;  // "kin scratch"
   int H;                                                                           // aliases kin scratch
   int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim;
+  int stash;     // 4 doubles parked across the step loop
   int cmask;     // per dof: 64-bit mask of the contacts whose Jacobian touches the dof
   int cond, Jb, cpar, cW, cp, jar, D, aref;
   int maxlim;    // capacity of limit rows (2 per hinge); D holds maxlim limit entries then one per contact
@@ -1317,6 +1321,9 @@ __device__ __forceinline__ void mj_steps(C& c, int nsteps) {
   for (int sub = 0; sub < 4 * nsteps; sub++) {
     const int stage = sub & 3;
     c.use_prev = (c.L.warm_mode == 1 && stage != 0) ? 1 : 0;
+    // make the lane id opaque per iteration: stops the compiler from hoisting hundreds of lane-dependent address
+    // computations out of this loop (they would be spilled to scratch under the 256-register budget)
+    asm volatile("" : "+v"(c.lane));
     forward(c);
     if (stage == 0) {
       if (lane < nq) q0 = S(qpos)[lane];
@@ -1503,29 +1510,32 @@ __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
 extern __shared__ double smem_dyn[];
 
 template <int NV>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) sumo_step_kernel(const Params* P, StepArgs a) {
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE, SUMO_WPE))) sumo_step_kernel(const Params* P, StepArgs a) {
   Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
   const int e = blockIdx.x, lane = c.lane;
   if (e >= a.N) return;
   load_state(c, a, e);
-  const float* act = a.actions + (size_t)e * 2 * a.act_stride;
   if (lane < mdl.nu) {
+    const float* act0 = a.actions + (size_t)e * 2 * a.act_stride;
     int ag = lane >= MI(agent_uadr)[1] ? 1 : 0;
-    S(ctrl)[lane] = (double)act[ag * a.act_stride + (lane - MI(agent_uadr)[ag])];
+    S(ctrl)[lane] = (double)act0[ag * a.act_stride + (lane - MI(agent_uadr)[ag])];
   }
-  int* cnt = a.counters + 4 * e;
-  int num_steps = cnt[0], reset_count = cnt[1];
-  double* st = a.state + (size_t)e * a.state_stride;
-  double ep_ret = st[mdl.nq + 2 * mdl.nv], ep_dense = st[mdl.nq + 2 * mdl.nv + 1];
   SYNC();
-  double before[2][2];
-  for (int g = 0; g < 2; g++) { int qa = MI(agent_qposadr)[g]; before[g][0] = S(qpos)[qa]; before[g][1] = S(qpos)[qa + 1]; }
+  // torso xy before the step (agents.py:216-217) is parked in LDS so nothing but the context stays live across the
+  // twenty forward-dynamics evaluations (keeps the kernel within the two-waves-per-SIMD register budget)
+  if (lane < 2) { int qa = MI(agent_qposadr)[lane]; S(stash)[2 * lane] = S(qpos)[qa]; S(stash)[2 * lane + 1] = S(qpos)[qa + 1]; }
   SYNC();
   PROF(17);
   mj_steps(c, mdl.frame_skip);
   PROF(18);
+  const float* act = a.actions + (size_t)e * 2 * a.act_stride;
+  int* cnt = a.counters + 4 * e;
+  int num_steps = cnt[0], reset_count = cnt[1];
+  double* st = a.state + (size_t)e * a.state_stride;
+  double ep_ret = st[mdl.nq + 2 * mdl.nv], ep_dense = st[mdl.nq + 2 * mdl.nv + 1];
+  double before[2][2] = {{S(stash)[0], S(stash)[1]}, {S(stash)[2], S(stash)[3]}};
   // ---- game rules (sumo.py:120-202), evaluated redundantly by every lane (wave-uniform result)
   double after[2][2], z[2];
   for (int g = 0; g < 2; g++) {
@@ -1607,7 +1617,7 @@ __global__ void __launch_bounds__(WAVE) sumo_reset_kernel(const Params* P, StepA
 }
 
 template <int NV>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) sumo_forward_kernel(const Params* P, StepArgs a) {
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE, SUMO_WPE))) sumo_forward_kernel(const Params* P, StepArgs a) {
   Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
@@ -1896,7 +1906,7 @@ static void build_layout(sumo_engine* E) {
     L.msize = (nv0 + nv1) * L.mld;
   }
   L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = take(nv);
-  L.search = take(nv); L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv);
+  L.search = take(nv); L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv); L.stash = take(4);
   // contact records live from the narrow phase to the Jacobian build only: they borrow the mass matrix's storage
   if (L.msize < 14 * L.maxcon) L.msize = 14 * L.maxcon;
   L.M = take(L.msize);
