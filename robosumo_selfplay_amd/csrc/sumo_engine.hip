@@ -55,6 +55,8 @@ struct Layout {  // LDS offsets in doubles unless noted
   int ld;        // leading dimension of H (odd)
   int mld, msize, d1;  // mass matrix: one dense block per agent tree, leading dim mld (odd); d1 = first dof of agent 1
   int maxcon, maxefc, maxcand;
+  int jbcap;     // capacity of the contact-Jacobian pool in 24-double halves (3 rows x 8 slots); a contact between two
+                 // moving bodies takes two halves, a contact with the world one
   int warm_mode;  // 0: MuJoCo semantics (solver starts from qacc_warmstart of the previous mj_step); 1: RK stages 2-4 start
                   // from the previous stage's solution (same optimum within the solver tolerance, fewer Newton iterations)
   int qpos, qvel, warm, ctrl, x0, accv, acca, tmpv;
@@ -812,7 +814,19 @@ template <class C>
 __device__ __forceinline__ void make_constraint(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   KCONSTS();
-  const int lane = c.lane, nv = mdl.nv, ncon = c.ncon;
+  const int lane = c.lane, nv = mdl.nv;
+  // ---- Jacobian pool allocation (contact order): one 3x8 half per moving body of the contact
+  int ncon = c.ncon;
+  {
+    int nh = 0;
+    int* cb = c.si + c.L.con_b + 4 * (lane < ncon ? lane : 0);
+    if (lane < ncon) nh = (cb[0] != 0 && cb[1] != 0) ? 2 : 1;
+    int tot, pre = wave_excl_scan(nh, lane, &tot);
+    unsigned long long nofit = __ballot(lane < ncon && pre + nh > c.L.jbcap);
+    if (nofit) { int nfit = __builtin_ctzll(nofit); c.ndropped += ncon - nfit; ncon = nfit; c.ncon = nfit; }
+    if (lane < ncon) cb[3] = (24 * pre) | ((nh == 2) << 20);
+    SYNC();
+  }
   const double timestep = MF(opt)[SUMO_OPT_TIMESTEP];
   const double def_solref[2] = {0.02, 1.0};
   const double def_solimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
@@ -879,14 +893,20 @@ __device__ __forceinline__ void make_constraint(C& c) {
   unsigned char* slotof = c.sb + c.L.b_slotof;
   for (int i = lane; i < ncon * nv; i += WAVE) slotof[i] = 0xFF;
   SYNC();
-  // compact contact Jacobians: 3 base rows (normal, t1, t2) x 16 slots (chain of body1 | chain of body2)
+  // compact contact Jacobians: 3 base rows (normal, t1, t2) x ns slots.  Two moving bodies: ns = 16 (chain of body1,
+  // sign -, then chain of body2, sign +); one moving body (contact with the world): ns = 8, that body's chain only.
   for (int idx = lane; idx < ncon * 16; idx += WAVE) {
-    int ci = idx >> 4, s = idx & 15, side = s >> 3, pos = s & 7;
+    int ci = idx >> 4, s = idx & 15;
     const int* cb = c.si + c.L.con_b + 4 * ci;
+    const int two = cb[3] >> 20, jb = cb[3] & 0xFFFFF, ns = two ? 16 : 8;
+    int side, pos = s & 7;
+    bool slot_ok = true;
+    if (two) side = s >> 3;
+    else { side = cb[0] != 0 ? 0 : 1; slot_ok = s < 8; }
     int body = side ? cb[1] : cb[0], other = side ? cb[0] : cb[1];
     int dof = -1, ag = 0;
     double j0 = 0, j1 = 0, j2 = 0;
-    if (body != 0) {
+    if (slot_ok && body != 0) {
       int la = CHLEN_AGENT(body);
       ag = la >> 8;
       if (pos < (la & 0xFF)) {
@@ -911,8 +931,10 @@ __device__ __forceinline__ void make_constraint(C& c) {
       atomicOr((unsigned long long*)S(cmask) + dof, 1ull << ci);
     }
     ((signed char*)c.sb)[c.L.b_dofidx + idx] = (signed char)dof;
-    double* Jb = S(Jb) + 48 * ci;
-    Jb[s] = j0; Jb[16 + s] = j1; Jb[32 + s] = j2;
+    if (slot_ok) {
+      double* Jb = S(Jb) + jb;
+      Jb[s] = j0; Jb[ns + s] = j1; Jb[2 * ns + s] = j2;
+    }
   }
   SYNC();
   PROF(7);
@@ -924,11 +946,12 @@ template <class C>
 __device__ __forceinline__ void contact_Jx(C& c, const double* x) {
   for (int idx = c.lane; idx < 3 * c.ncon; idx += WAVE) {
     int ci = idx / 3, a = idx - 3 * ci;
-    const double* Jb = S(Jb) + 48 * ci + 16 * a;
+    const int info = (c.si + c.L.con_b)[4 * ci + 3], ns = (info >> 20) ? 16 : 8;
+    const double* Jb = S(Jb) + (info & 0xFFFFF) + ns * a;
     const signed char* di = (const signed char*)c.sb + c.L.b_dofidx + 16 * ci;
     double xv[16], jv[16];
 #pragma unroll
-    for (int s = 0; s < 16; s++) { int d = di[s]; xv[s] = x[d < 0 ? 0 : d]; jv[s] = Jb[s]; }
+    for (int s = 0; s < 16; s++) { int d = di[s]; xv[s] = x[d < 0 ? 0 : d]; double jq = Jb[s]; jv[s] = s < ns ? jq : 0.0; }
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
     for (int s = 0; s < 16; s += 4) { a0 += jv[s] * xv[s]; a1 += jv[s + 1] * xv[s + 1]; a2 += jv[s + 2] * xv[s + 2]; a3 += jv[s + 3] * xv[s + 3]; }
@@ -1139,9 +1162,10 @@ __device__ __forceinline__ void newton_solve(C& c) {
       for (unsigned long long mk = ((const unsigned long long*)S(cmask))[lane]; mk; mk &= mk - 1) {
         int ci = __builtin_ctzll(mk);
         int s = slotof[ci * nv + lane];
-        const double* Jb = S(Jb) + 48 * ci;
+        const int info = (c.si + c.L.con_b)[4 * ci + 3], ns = (info >> 20) ? 16 : 8;
+        const double* Jb = S(Jb) + (info & 0xFFFFF);
         const double* cp = S(cp) + 3 * ci;
-        qc += Jb[s] * cp[0] + Jb[16 + s] * cp[1] + Jb[32 + s] * cp[2];
+        qc += Jb[s] * cp[0] + Jb[ns + s] * cp[1] + Jb[2 * ns + s] * cp[2];
       }
       g = Ma - S(qsm)[lane] - qc;
       S(grad)[lane] = g;
@@ -1174,9 +1198,10 @@ __device__ __forceinline__ void newton_solve(C& c) {
         for (unsigned long long mk = mreg[m]; mk; mk &= mk - 1) {
           int ci = __builtin_ctzll(mk);
           int si = slotof[ci * nv + i], sj = slotof[ci * nv + jj];
-          const double* Jb = S(Jb) + 48 * ci;
+          const int info = (c.si + c.L.con_b)[4 * ci + 3], ns = (info >> 20) ? 16 : 8;
+          const double* Jb = S(Jb) + (info & 0xFFFFF);
           const double* W = S(cW) + 6 * ci;
-          double a0 = Jb[si], a1 = Jb[16 + si], a2 = Jb[32 + si], b0 = Jb[sj], b1 = Jb[16 + sj], b2 = Jb[32 + sj];
+          double a0 = Jb[si], a1 = Jb[ns + si], a2 = Jb[2 * ns + si], b0 = Jb[sj], b1 = Jb[ns + sj], b2 = Jb[2 * ns + sj];
           h += a0 * (W[0] * b0 + W[1] * b1 + W[2] * b2) + a1 * (W[1] * b0 + W[3] * b1) + a2 * (W[2] * b0 + W[4] * b2);
         }
         hreg[m] = h;
@@ -1913,7 +1938,8 @@ static void build_layout(sumo_engine* E) {
   L.cond = L.M;
   // body frames / joint anchors / RNE temporaries are dead before the contact Jacobians are written: same storage
   {
-    int jb0 = o, need = 19 * nb + 6 * nj, jbsz = 48 * L.maxcon;
+    L.jbcap = L.maxcon + L.maxcon / 3;
+    int jb0 = o, need = 19 * nb + 6 * nj, jbsz = 24 * L.jbcap + 16;
     L.Jb = take(jbsz > need ? jbsz : need);
     int q = jb0;
     L.xpos = q; q += 3 * nb; L.xquat = q; q += 4 * nb; L.xanchor = q; q += 3 * nj; L.xaxis = q; q += 3 * nj;
