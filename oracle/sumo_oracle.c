@@ -426,16 +426,16 @@ static int sphere_box(contact_t* c, double margin, const double* sp, double r, c
   return 1;
 }
 /* derivative (up to a factor 2) of the squared distance from segment point c + t*a to the box, box frame */
-static double seg_box_dgrad(const double* cc, const double* a, const double* bs, double t) {
-  double g = 0;
+static double seg_box_dgrad(const double* cc, const double* a, const double* bs, double t, int skip) {
+  double g = 0; /* skip: the coordinate that sits exactly on a box face at t (its own breakpoint) contributes exactly 0 */
   for (int k = 0; k < 3; k++) {
+    if (k == skip) continue;
     double p = cc[k] + t * a[k];
     if (p > bs[k]) g += a[k] * (p - bs[k]);
     else if (p < -bs[k]) g += a[k] * (p + bs[k]);
   }
   return g;
 }
-#define SEGBOX_BISECT 32
 /* capsule-box: both end spheres, plus the sphere at the interior closest point of the segment when the
  * squared-distance derivative changes sign strictly inside the segment (documented deviation from MuJoCo's
  * mjc_CapsuleBox feature search, whose source is not available offline). */
@@ -450,14 +450,22 @@ static int capsule_box(contact_t* c, double margin, const double* cp, const doub
   double t[3] = {cp[0] - bp[0], cp[1] - bp[1], cp[2] - bp[2]}, cc[3], a[3];
   mulmatTvec3(cc, bm, t);
   mulmatTvec3(a, bm, axw);
-  double glo = seg_box_dgrad(cc, a, bs, -1.0), ghi = seg_box_dgrad(cc, a, bs, 1.0);
+  double glo = seg_box_dgrad(cc, a, bs, -1.0, -1), ghi = seg_box_dgrad(cc, a, bs, 1.0, -1);
   if (glo < 0 && ghi > 0) {
+    /* the derivative is piecewise linear and non-decreasing in t: bracket the root between consecutive breakpoints
+     * (where a coordinate crosses a box face), then interpolate exactly */
     double lo = -1, hi = 1;
-    for (int it = 0; it < SEGBOX_BISECT; it++) {
-      double mid = 0.5 * (lo + hi);
-      if (seg_box_dgrad(cc, a, bs, mid) > 0) hi = mid; else lo = mid;
+    for (int k = 0; k < 3; k++) {
+      double ra = 1.0 / a[k]; /* a[k] == 0: the breakpoints are inf / nan and fail the comparisons below */
+      for (int sg = 0; sg < 2; sg++) {
+        double tb = ((sg ? -bs[k] : bs[k]) - cc[k]) * ra;
+        if (tb > lo && tb < hi) {
+          double gb = seg_box_dgrad(cc, a, bs, tb, k);
+          if (gb > 0) { hi = tb; ghi = gb; } else { lo = tb; glo = gb; }
+        }
+      }
     }
-    double ts = 0.5 * (lo + hi);
+    double ts = lo - glo * (hi - lo) / (ghi - glo);
     double e[3] = {cp[0] + ts * axw[0], cp[1] + ts * axw[1], cp[2] + ts * axw[2]};
     n += sphere_box(c + n, margin, e, cs[0], bp, bm, bs);
   }

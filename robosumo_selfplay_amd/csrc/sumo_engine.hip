@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "../../include/sumo_hip.h"
@@ -32,7 +33,6 @@
 #define MAXCHAIN 8   /* dofs on the path root -> body (free joint 6 + hip + ankle) */
 #define MAXBCHAIN 4  /* bodies on the path root -> body */
 #define PI_D 3.14159265358979323846
-#define SEGBOX_BISECT 32
 #define RNG_NORMAL_BASE 64
 
 // ---------------------------------------------------------------------------------------------------------
@@ -57,6 +57,7 @@ struct Layout {  // LDS offsets in doubles unless noted
   int maxcon, maxefc, maxcand;
   int jbcap;     // capacity of the contact-Jacobian pool in 24-double halves (3 rows x 8 slots); a contact between two
                  // moving bodies takes two halves, a contact with the world one
+  int tree_ok;    // the dof tree has the shape tree_factor_solve assumes (checked in build_layout)
   int warm_mode;  // 0: MuJoCo semantics (solver starts from qacc_warmstart of the previous mj_step); 1: RK stages 2-4 start
                   // from the previous stage's solution (same optimum within the solver tolerance, fewer Newton iterations)
   int qpos, qvel, warm, ctrl, x0, accv, acca, tmpv;
@@ -70,7 +71,7 @@ struct Layout {  // LDS offsets in doubles unless noted
   int stat_d;    // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wpos[3*nworld] | waxis[3*nworld]
   int i_base;  // start of int region (in doubles)
   // int region offsets (in ints, relative to int base)
-  int con_b, plist, prlist, lim_dof, lim_sign, limrow;  // limrow[dof] = first limit row | count << 8
+  int con_b, lim_dof, lim_sign, limrow;  // limrow[dof] = first limit row | count << 8
   int b_dofidx;  // byte offset (relative to int base): signed char [16 * maxcon], dof of each Jacobian slot or -1
   int stat_i;    // static int tables: ctype[nc] | cbody[nc] | chain[2*nbody] | chlen_agent[nbody]
   int b_slotof;  // byte offset (relative to int base, in bytes)
@@ -283,9 +284,12 @@ __device__ __forceinline__ void sphere_box(Con1& c, double margin, const double*
   for (int k = 0; k < 3; k++) c.pos[k] = pw[k] + bp[k];
   c.ok = 1;
 }
-__device__ __forceinline__ double seg_box_dgrad(const double* cc, const double* a, const double* bs, double t) {
+// `skip`: coordinate that sits exactly on a box face at t (its own breakpoint) and contributes exactly 0
+__device__ __forceinline__ double seg_box_dgrad(const double* cc, const double* a, const double* bs, double t, int skip = -1) {
   double g = 0;
+#pragma unroll
   for (int k = 0; k < 3; k++) {
+    if (k == skip) continue;
     double p = cc[k] + t * a[k];
     if (p > bs[k]) g += a[k] * (p - bs[k]);
     else if (p < -bs[k]) g += a[k] * (p + bs[k]);
@@ -322,7 +326,7 @@ struct LaneRec {
 struct Params {  // lives in device memory; read through scalar / per-lane loads
   sumo_model_t mdl; Aux aux; Layout L;
   const LaneRec* lanes;     // [64]
-  const int* pair_rec;      // [PRmax*64]  c1 | c2<<8 | plane<<16 | valid<<17
+  const int* pair_rec;      // [PRmax*64]  c1 | c2<<8 | plane<<16 | valid<<17 | kind<<18 (see build_aux)
   const float* pair_bound;  // conservative (rounded-up) bounding-sphere reach: margin + rbound1 + rbound2 (plane: margin + rbound2)
 };
 
@@ -342,7 +346,7 @@ struct Ctx {
   unsigned char* sb;  // LDS byte region (slotof)
   int lane;
   // per-forward scalars (wave-uniform)
-  int ncon, nlim, nefc, ndropped, use_prev, hblk;  // hblk: no contact couples the two agents -> H is block diagonal
+  int ncon, nlim, nefc, ndropped, use_prev, htree;  // htree: every contact has one moving body -> H is tree-sparse like M
 #ifdef SUMO_PROFILE
   long long tprev;
   unsigned long long prof[20];
@@ -630,8 +634,10 @@ __device__ __forceinline__ void make_frame(double* f) {
 template <class C>
 __device__ __forceinline__ void collision(C& c) {
   const int lane = c.lane, nb = c.P->mdl.nbody;
-  int* plist = c.si + c.L.plist;    // pair ids of broad-phase survivors (pair order preserved)
-  int* prlist = c.si + c.L.prlist;  // their packed centre records
+  // survivors of the broad phase (pair order preserved): pair ids and packed centre records.  The queue borrows the
+  // constraint-row arrays (jar / aref), which are dead until make_constraint.
+  int* plist = (int*)S(jar);
+  int* prlist = (int*)S(aref);
   int ncand = 0, ncon = 0, dropped = 0;
   const int* prp = launder_ptr(c.prp);
   const float* pbp = launder_ptr(c.pbp);
@@ -640,13 +646,32 @@ __device__ __forceinline__ void collision(C& c) {
     const int rec = prp[WAVE * r];
     int pass = 0;
     if (rec & (1 << 17)) {
-      const int c1 = rec & 0xFF, c2 = (rec >> 8) & 0xFF;
+      const int c1 = rec & 0xFF, c2 = (rec >> 8) & 0xFF, kind = (rec >> 18) & 3;
       const double* p1 = S(xipos) + 3 * c1;
       const double* p2 = S(xipos) + 3 * c2;
       const double bound = (double)pbp[WAVE * r];
       double t[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
       if (rec & (1 << 16)) pass = !(dot3(t, S(gaxis) + 3 * c1) > bound);
-      else pass = !(dot3(t, t) > bound * bound);
+      else {
+        double d2;
+        if (kind == 1) {         // c2 is a static box: exact distance from the other geom's centre to the box
+          const double* bm = WBOX(c2 - nb);
+          double ctr[3];
+          mulmatTvec3(ctr, bm, t);
+          d2 = 0;
+          for (int k = 0; k < 3; k++) { double e = fabs(ctr[k]) - bm[9 + k]; if (e > 0) d2 += e * e; }
+        } else if (kind >= 2) {  // one side is a static capsule (border rod): distance from the other centre to its axis segment
+          const int w = kind == 2 ? c1 : c2;
+          const double* g = S(gaxis) + 3 * w;
+          const double hl = CSIZE(w)[1];
+          double x = dot3(t, g);
+          x = x > hl ? hl : (x < -hl ? -hl : x);
+          // (kind 2: t points from the rod centre to the other geom; kind 3: the opposite -- only |t - g x|^2 matters)
+          double d[3] = {t[0] - g[0] * x, t[1] - g[1] * x, t[2] - g[2] * x};
+          d2 = dot3(d, d);
+        } else d2 = dot3(t, t);
+        pass = !(d2 > bound * bound);
+      }
     }
     unsigned long long bal = __ballot(pass);
     int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
@@ -731,12 +756,22 @@ __device__ __forceinline__ void collision(C& c) {
             mulmatTvec3(a, bm, axw);
             double glo = seg_box_dgrad(cc, a, bs, -1.0), ghi = seg_box_dgrad(cc, a, bs, 1.0);
             if (glo < 0 && ghi > 0) {
+              // the derivative is piecewise linear and non-decreasing in t: bracket the root between consecutive
+              // breakpoints (where a coordinate crosses a box face), then interpolate exactly
               double lo = -1, hi = 1;
-              for (int it = 0; it < SEGBOX_BISECT; it++) {
-                double mid = 0.5 * (lo + hi);
-                if (seg_box_dgrad(cc, a, bs, mid) > 0) hi = mid; else lo = mid;
+#pragma unroll
+              for (int k = 0; k < 3; k++) {
+                const double ra = fast_rcp(a[k]);
+#pragma unroll
+                for (int sg = 0; sg < 2; sg++) {
+                  const double tb = ((sg ? -bs[k] : bs[k]) - cc[k]) * ra;
+                  if (tb > lo && tb < hi) {
+                    const double gb = seg_box_dgrad(cc, a, bs, tb, k);
+                    if (gb > 0) { hi = tb; ghi = gb; } else { lo = tb; glo = gb; }
+                  }
+                }
               }
-              double ts = 0.5 * (lo + hi);
+              double ts = lo - glo * (hi - lo) / (ghi - glo);
               for (int q = 0; q < 3; q++) e[q] = p1[q] + ts * axw[q];
               sphere_box(cs[2], margin, e, s1[0], p2, bm, bs);
             }
@@ -862,12 +897,12 @@ __device__ __forceinline__ void make_constraint(C& c) {
   c.nlim = nlim;
   c.nefc = nlim + 4 * ncon;
   {
-    int cross = 0;
+    int two = 0;
     for (int ci = lane; ci < ncon; ci += WAVE) {
       const int* cb = c.si + c.L.con_b + 4 * ci;
-      if (cb[0] != 0 && cb[1] != 0 && (CHLEN_AGENT(cb[0]) >> 8) != (CHLEN_AGENT(cb[1]) >> 8)) cross = 1;
+      if (cb[0] != 0 && cb[1] != 0) two = 1;
     }
-    c.hblk = __ballot(cross) == 0ull;
+    c.htree = c.L.tree_ok && __ballot(two) == 0ull;
   }
   // contact row parameters (same for the 4 pyramid edges of a contact)
   for (int ci = lane; ci < ncon; ci += WAVE) {
@@ -991,53 +1026,31 @@ __device__ __forceinline__ double dense_Mx(const C& c, const double* x) {
   return acc;
 }
 
-// Solve A x = b for a symmetric positive definite A held in LDS (lower triangle, leading dim ld): lane i loads row i
+// Solve A x = b for a symmetric positive definite A held in LDS (packed lower triangle): lane i loads row i
 // into registers, the wave runs a right-looking LDL^T entirely with v_readlane broadcasts (no LDS traffic, no barriers;
-// fully unrolled so every register index is static), forward-substitutes, transposes L through LDS once (`T`, nv x ld)
+// fully unrolled so every register index is static), forward-substitutes, transposes L through LDS once (`T`, packed)
 // and back-substitutes.  Lane i holds b_i on entry and returns x_i.  *fail is wave-uniform.
-template <bool BLOCKDIAG, class C>
-__device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* T, double b, int* fail, int blk) {
+// This is the general path (a contact between two moving bodies fills H outside the tree pattern).
+template <class C>
+__device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* T, double b, int* fail) {
   constexpr int NV = C::NV;
   const int lane = c.lane;
   const int li = lane < NV ? lane : NV - 1;
   double a[NV];
-  if (BLOCKDIAG) {  // A is the block-diagonal mass matrix
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-      int kk = k <= li ? k : li;
-      a[k] = SAME_TREE(li, kk) ? A[MIDX(li, kk)] : 0.0;
-    }
-  } else {  // A is the packed lower triangle (Hessian)
-#pragma unroll
-    for (int k = 0; k < NV; k++) a[k] = A[HP(li, (k <= li ? k : li))];
-  }
+  for (int k = 0; k < NV; k++) a[k] = A[HP(li, (k <= li ? k : li))];
   double dinv = 0;
   int bad = 0;
-  if (blk && c.L.d1 * 2 == NV) {  // matrix is block diagonal (mass matrix; Hessian without agent-agent contacts)
-    // two equal independent blocks: columns of block 0 never touch rows of block 1 (those entries are exact zeros)
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-      double ajj = readlane_f64(a[j], j);
-      if (ajj < MINVAL) bad = 1;
-      double r = fast_rcp(ajj);
-      double lij = a[j] * r;
+  for (int j = 0; j < NV; j++) {
+    double ajj = readlane_f64(a[j], j);
+    if (ajj < MINVAL) bad = 1;
+    double r = fast_rcp(ajj);
+    double lij = a[j] * r;
 #pragma unroll
-      for (int k = j + 1; k < (j < NV / 2 ? NV / 2 : NV); k++) a[k] -= lij * readlane_f64(a[j], k);
-      if (lane == j) dinv = r;
-      a[j] = lij;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < NV; j++) {
-      double ajj = readlane_f64(a[j], j);
-      if (ajj < MINVAL) bad = 1;
-      double r = fast_rcp(ajj);
-      double lij = a[j] * r;
-#pragma unroll
-      for (int k = j + 1; k < NV; k++) a[k] -= lij * readlane_f64(a[j], k);  // lanes < k only touch unused entries
-      if (lane == j) dinv = r;
-      a[j] = lij;
-    }
+    for (int k = j + 1; k < NV; k++) a[k] -= lij * readlane_f64(a[j], k);  // lanes < k only touch unused entries
+    if (lane == j) dinv = r;
+    a[j] = lij;
   }
   double y = b;
 #pragma unroll
@@ -1065,6 +1078,148 @@ __device__ __forceinline__ double ldl_solve_rows(C& c, const double* A, double* 
   SYNC();
   *fail = bad;
   return y;
+}
+
+// ---- tree-sparse factorisation ----------------------------------------------------------------------------------
+// Every agent of the nine scenes is a free body (6 dofs) carrying legs of two hinges (hip, ankle), with the dofs ordered
+// root 0..5, then (hip, ankle) per leg (checked on the host, Layout::tree_ok).  The mass matrix -- and the Newton
+// Hessian as long as every contact touches a single moving body -- is then nonzero only between a dof and its
+// ancestors: lane i keeps row i as row[p] = A[i][ancestor at chain position p] (root dof m: p <= m; hip: 0..5 root,
+// 6 diag; ankle: 0..5 root, 6 hip, 7 diag).  A x = b is solved by block elimination (MuJoCo's mj_factorM order, leaves
+// first): the 2x2 leg blocks are inverted in their own lanes, the 6x6 Schur complement of each root is accumulated by
+// the six root lanes and factorised redundantly by every lane of the agent.  No fill-in, five short phases.
+#define DPP_SWAP_PAIR 0xB1  /* quad_perm [1,0,3,2]: exchange with the neighbouring lane (hip <-> ankle; hips sit on even lanes) */
+__device__ __forceinline__ double pair_swap_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, DPP_SWAP_PAIR, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, DPP_SWAP_PAIR, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// row <- tree row `lane` of M + diag_add on the diagonal (+ J^T W J of the contacts touching this dof)
+template <class C>
+__device__ __forceinline__ void tree_rows(C& c, double (&row)[8], double diag_add, bool with_contacts) {
+  const int lane = c.lane, nv = c.P->mdl.nv, d1 = c.L.d1;
+  const int li = lane < nv ? lane : 0;
+  const int il = li >= d1 ? li - d1 : li;           // dof index inside the agent
+  const int pos = il < 6 ? il : 6 + (il & 1);       // chain position of the dof itself
+  const double* Mrow = S(M) + li * c.L.mld;
+#pragma unroll
+  for (int p = 0; p < 6; p++) row[p] = Mrow[p] + (p == il ? diag_add : 0.0);
+  const double mh = Mrow[il < 6 ? 0 : il - (il & 1)], md = Mrow[il];   // column of the leg's hip, own diagonal
+  row[6] = il < 6 ? 0.0 : ((il & 1) ? mh : md + diag_add);
+  row[7] = (il >= 6 && (il & 1)) ? md + diag_add : 0.0;
+  if (with_contacts && lane < nv) {
+    for (unsigned long long mk = ((const unsigned long long*)S(cmask))[lane]; mk; mk &= mk - 1) {
+      const int ci = __builtin_ctzll(mk);
+      const double* Jb = S(Jb) + ((c.si + c.L.con_b)[4 * ci + 3] & 0xFFFFF);   // one moving body: 3 rows x 8 chain slots
+      const double* W = S(cW) + 6 * ci;
+      const double a0 = Jb[pos], a1 = Jb[8 + pos], a2 = Jb[16 + pos];
+      const double u0 = W[0] * a0 + W[1] * a1 + W[2] * a2, u1 = W[1] * a0 + W[3] * a1, u2 = W[2] * a0 + W[4] * a2;
+#pragma unroll
+      for (int p = 0; p < 8; p++) row[p] += u0 * Jb[p] + u1 * Jb[8 + p] + u2 * Jb[16 + p];   // slots past `pos` are unused entries
+    }
+  }
+}
+
+template <class C>
+__device__ __forceinline__ double tree_factor_solve(C& c, const double (&row)[8], double b, int* fail) {
+  const int lane = c.lane, nv = c.P->mdl.nv, d1 = c.L.d1;
+  const bool act = lane < nv;
+  const int B = lane >= d1 ? d1 : 0, il = lane - B;
+  const int nvg = lane >= d1 ? nv - d1 : d1;        // dofs of this lane's agent
+  const bool isleg = act && il >= 6, iship = !(il & 1);
+  double* ROW = S(H);           // [nv][8] rows (root rows are overwritten by the Schur complement: [0..5] S, [6] rhs)
+  double* WW = S(H) + 8 * nv;   // [nv][6] leg dofs: row of A_ll^-1 A_lr
+  double* Y = S(tmpv);          // [nv]    leg dofs: A_ll^-1 b_l
+  int bad = 0;
+  // ---- leg blocks: [[dh, o], [o, da]] (hip, ankle); each lane computes its own row of the inverse applied to (A_lr | b_l)
+  double pr[8];
+#pragma unroll
+  for (int p = 0; p < 8; p++) pr[p] = pair_swap_f64(row[p]);
+  const double pb = pair_swap_f64(b);
+  const double d_own = iship ? row[6] : row[7], d_par = iship ? pr[7] : pr[6], off = iship ? pr[6] : row[6];
+  const double det = d_own * d_par - off * off;
+  if (isleg && (d_par < MINVAL || det < MINVAL * d_par)) bad = 1;   // pivots of the 2x2 LDL: d_par, det / d_par
+  const double idet = fast_rcp(det);
+  double w[6];
+#pragma unroll
+  for (int p = 0; p < 6; p++) w[p] = (d_par * row[p] - off * pr[p]) * idet;
+  const double y = (d_par * b - off * pb) * idet;
+  if (act) {
+#pragma unroll
+    for (int p = 0; p < 8; p++) ROW[8 * lane + p] = row[p];
+    if (isleg) {
+#pragma unroll
+      for (int p = 0; p < 6; p++) WW[6 * lane + p] = w[p];
+      Y[lane] = y;
+    }
+  }
+  SYNC();
+  // ---- Schur complement of the root block: S = A_rr - A_rl A_ll^-1 A_lr, rhs' = b_r - A_rl A_ll^-1 b_l (root lane m: row m)
+  if (act && il < 6) {
+    double s[6], br = b;
+#pragma unroll
+    for (int p = 0; p < 6; p++) s[p] = row[p];
+#pragma unroll 4
+    for (int d = B + 6; d < B + nvg; d++) {
+      const double am = ROW[8 * d + il];
+      const double* wd = WW + 6 * d;
+#pragma unroll
+      for (int p = 0; p < 6; p++) s[p] -= am * wd[p];
+      br -= am * Y[d];
+    }
+#pragma unroll
+    for (int p = 0; p < 6; p++) ROW[8 * lane + p] = s[p];
+    ROW[8 * lane + 6] = br;
+  }
+  SYNC();
+  // ---- 6x6 LDL^T + solve, redundantly in every lane of the agent
+  double L[6][6], xr[6];
+  {
+    const double* Sg = ROW + 8 * B;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) L[i][j] = Sg[8 * i + j];
+      xr[i] = Sg[8 * i + 6];
+    }
+    double rinv[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      if (act && L[j][j] < MINVAL) bad = 1;
+      rinv[j] = fast_rcp(L[j][j]);
+      double u[6];
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) u[i] = L[i][j];
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) {
+        const double lij = u[i] * rinv[j];
+#pragma unroll
+        for (int k = j + 1; k <= i; k++) L[i][k] -= lij * u[k];
+        L[i][j] = lij;
+      }
+    }
+#pragma unroll
+    for (int i = 1; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < i; j++) xr[i] -= L[i][j] * xr[j];
+#pragma unroll
+    for (int i = 0; i < 6; i++) xr[i] *= rinv[i];
+#pragma unroll
+    for (int i = 4; i >= 0; i--)
+#pragma unroll
+      for (int k = i + 1; k < 6; k++) xr[i] -= L[k][i] * xr[k];
+  }
+  // ---- back substitution into the legs: x_l = A_ll^-1 b_l - (A_ll^-1 A_lr) x_r
+  double x = y;
+#pragma unroll
+  for (int p = 0; p < 6; p++) x -= w[p] * xr[p];
+#pragma unroll
+  for (int p = 0; p < 6; p++) x = il == p ? xr[p] : x;
+  SYNC();
+  *fail = __ballot(bad) != 0ull;
+  return act ? x : 0.0;
 }
 
 // cost(x) = 1/2 (Ma - qfrc_smooth).(x - qacc_smooth) + sum_active 1/2 D jar^2
@@ -1177,7 +1332,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
     SYNC();
     // ---- Hessian H = M + J^T diag(D_active) J, lower triangle: entry-major gather (every lane a few entries).
     // All loads of the mass-matrix / mask words are issued before any store so they pipeline.
-    {
+    if (!c.htree) {
       const unsigned long long* cm = (const unsigned long long*)S(cmask);
       double hreg[C::EPL];
       unsigned long long mreg[C::EPL];
@@ -1215,7 +1370,14 @@ __device__ __forceinline__ void newton_solve(C& c) {
     SYNC();
     PROF(13);
     int hfail;
-    double sr = -ldl_solve_rows<false>(c, S(H), S(H), lane < nv ? S(grad)[lane] : 0.0, &hfail, c.hblk);
+    double sr;
+    if (c.htree) {  // every contact touches one moving body: H keeps the tree sparsity of M (see tree_factor_solve)
+      double row[8];
+      tree_rows(c, row, lane < nv ? S(dlim)[lane] : 0.0, ncon > 0);
+      sr = -tree_factor_solve(c, row, lane < nv ? S(grad)[lane] : 0.0, &hfail);
+    } else {
+      sr = -ldl_solve_rows(c, S(H), S(H), lane < nv ? S(grad)[lane] : 0.0, &hfail);
+    }
     if (hfail) break;
     if (lane < nv) S(search)[lane] = sr;
     SYNC();
@@ -1300,7 +1462,20 @@ __device__ __forceinline__ void forward(C& c) {
   SYNC();
   // qacc_smooth = M^-1 qfrc_smooth
   int mfail;
-  double as = ldl_solve_rows<true>(c, S(M), S(H), lane < nv ? S(qsm)[lane] : 0.0, &mfail, 1);
+  double as;
+  if (c.L.tree_ok) {
+    double row[8];
+    tree_rows(c, row, 0.0, false);
+    as = tree_factor_solve(c, row, lane < nv ? S(qsm)[lane] : 0.0, &mfail);
+  } else {  // unknown tree shape: pack M into the Hessian buffer and use the dense factorisation
+#pragma unroll
+    for (int m = 0; m < C::EPL; m++) {
+      unsigned e = c.ent[m];
+      if (e != 0xFFFFu) { int i = e >> 8, jj = e & 0xFF; S(H)[HP(i, jj)] = SAME_TREE(i, jj) ? S(M)[MIDX(i, jj)] : 0.0; }
+    }
+    SYNC();
+    as = ldl_solve_rows(c, S(H), S(H), lane < nv ? S(qsm)[lane] : 0.0, &mfail);
+  }
   if (mfail) as = 0.0;
   if (lane < nv) S(asmo)[lane] = as;
   SYNC();
@@ -1662,7 +1837,11 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+#ifdef SUMO_DEV_NV  /* development builds: compile a single kernel variant */
+#define SUMO_FOR_NV(X) X(SUMO_DEV_NV)
+#else
 #define SUMO_FOR_NV(X) X(28) X(32) X(36) X(40) X(44)
+#endif
 static thread_local char g_err[512];
 extern "C" const char* sumo_last_error(void) { return g_err; }
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return code; } while (0)
@@ -1884,11 +2063,23 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
     for (int p = 0; p < m->npair; p++) {
       int g1 = SUMO_I(m, pair_geom1)[p], g2 = SUMO_I(m, pair_geom2)[p];
       int plane = gtype[g1] == SUMO_GEOM_PLANE;
+      // static world geoms get a tighter test than bounding spheres: exact point-box distance for boxes (kind 1), distance
+      // to the axis segment for capsules / the border rods (kind 2: geom1 is the static capsule, 3: geom2)
+      const int* gbody = SUMO_I(m, geom_bodyid);
+      auto is_cap = [&](int g) { return gtype[g] == SUMO_GEOM_CAPSULE || gtype[g] == SUMO_GEOM_CYLINDER; };
+      int kind = 0;
       double bound = SUMO_F(m, pair_margin)[p] + SUMO_F(m, geom_rbound)[g2] + (plane ? 0.0 : SUMO_F(m, geom_rbound)[g1]);
+      if (!plane && gbody[g2] == 0 && gtype[g2] == SUMO_GEOM_BOX && gbody[g1] != 0) {
+        kind = 1; bound = SUMO_F(m, pair_margin)[p] + SUMO_F(m, geom_rbound)[g1];
+      } else if (!plane && gbody[g1] == 0 && is_cap(g1) && gbody[g2] != 0) {
+        kind = 2; bound = SUMO_F(m, pair_margin)[p] + SUMO_F(m, geom_rbound)[g2] + SUMO_F(m, geom_size)[3 * g1];
+      } else if (!plane && gbody[g2] == 0 && is_cap(g2) && gbody[g1] != 0) {
+        kind = 3; bound = SUMO_F(m, pair_margin)[p] + SUMO_F(m, geom_rbound)[g1] + SUMO_F(m, geom_size)[3 * g2];
+      }
       float bf = (float)bound;
       while ((double)bf < bound) bf = nextafterf(bf, INFINITY);   // conservative: the broad phase may only over-include
       bf = nextafterf(bf, INFINITY);
-      E->pair_rec[p] = cen_of_geom[g1] | (cen_of_geom[g2] << 8) | (plane << 16) | (1 << 17);
+      E->pair_rec[p] = cen_of_geom[g1] | (cen_of_geom[g2] << 8) | (plane << 16) | (1 << 17) | (kind << 18);
       E->pair_bound[p] = bf;
     }
   }
@@ -1908,7 +2099,6 @@ static void build_layout(sumo_engine* E) {
   if (L.maxcon > 64) L.maxcon = 64;  // per-dof contact masks are 64 bits wide
   L.maxefc = 4 * L.maxcon + 2 * nhinge;
   { const char* wm = getenv("SUMO_WARM_MODE"); L.warm_mode = wm ? atoi(wm) : 0; }
-  L.maxcand = 64;  // queue of broad-phase survivors, drained by the narrow phase before it can overflow
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
   L.qpos = take(nq); L.qvel = take(nv); L.warm = take(nv); L.ctrl = take(nu);
@@ -1920,6 +2110,7 @@ static void build_layout(sumo_engine* E) {
   L.com = take(3 * m->nagent); L.cinert = take(10 * nb); L.cdof = take(6 * nv);
   L.H = kin0;
   if (o - kin0 < ntri) o = kin0 + ntri;
+  const int hsize = o - kin0;
   // centre positions / axes: bodies (rewritten every forward) then world geoms (static)
   L.xipos = take(3 * nc); L.gaxis = take(3 * nc);
   L.stat_d = take(E->aux.n_stat_d);
@@ -1929,6 +2120,21 @@ static void build_layout(sumo_engine* E) {
     L.mld = mx | 1;
     L.d1 = SUMO_I(m, agent_dofadr)[1];
     L.msize = (nv0 + nv1) * L.mld;
+  }
+  {  // shape tree_factor_solve relies on: two agents, each a free joint (6 dofs) + legs of (hip, ankle), bases even
+    const int* dpar = SUMO_I(m, dof_parentid);
+    int ok = m->nagent == 2 && SUMO_I(m, agent_dofadr)[0] == 0 && SUMO_I(m, agent_nv)[0] + SUMO_I(m, agent_nv)[1] == nv;
+    for (int g = 0; ok && g < 2; g++) {
+      int B = SUMO_I(m, agent_dofadr)[g], n = SUMO_I(m, agent_nv)[g];
+      if ((B & 1) || n < 6 || ((n - 6) & 1)) { ok = 0; break; }
+      if (dpar[B] != -1) ok = 0;
+      for (int k = 1; ok && k < 6; k++) if (dpar[B + k] != B + k - 1) ok = 0;
+      for (int d = B + 6; ok && d < B + n; d += 2) if (dpar[d] != B + 5 || dpar[d + 1] != d) ok = 0;
+    }
+    if (14 * nv > hsize) ok = 0;   // exchange buffers of the tree solver live in the Hessian region
+    L.tree_ok = ok;
+    const char* nt = getenv("SUMO_NO_TREE");
+    if (nt && atoi(nt)) L.tree_ok = 0;
   }
   L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = take(nv);
   L.search = take(nv); L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv); L.stash = take(4);
@@ -1949,10 +2155,12 @@ static void build_layout(sumo_engine* E) {
   L.cp = take(3 * L.maxcon);
   L.maxlim = 2 * nhinge;
   L.jar = take(L.maxefc); L.D = take(L.maxlim + L.maxcon); L.aref = take(L.maxefc);
+  // queue of broad-phase survivors (ints, inside jar / aref); drained by the narrow phase before it can overflow
+  L.maxcand = 2 * L.maxefc >= 192 ? 192 : (2 * L.maxefc) / WAVE * WAVE;
   L.i_base = o;
   int io = 0;
   auto itake = [&](int n) { int r = io; io += n; return r; };
-  L.con_b = itake(4 * L.maxcon); L.plist = itake(L.maxcand); L.prlist = itake(L.maxcand);
+  L.con_b = itake(4 * L.maxcon);
   L.stat_i = itake(E->aux.n_stat_i);
   L.lim_dof = itake(2 * nhinge);
   L.limrow = itake(nv);
@@ -2070,18 +2278,21 @@ extern "C" int sumo_dims(sumo_handle_t E, int32_t* o) {
 
 // kernel variants by nv (the factorisation is unrolled over a compile-time nv); the nine registered scenes have
 // nv in {28, 32, 36, 40, 44}
+template <class F>
+static bool for_kernel_variant(int nv, F&& f) {
+#define X(NVV) if (nv == NVV) { f(std::integral_constant<int, NVV>()); return true; }
+  SUMO_FOR_NV(X)
+#undef X
+  return false;
+}
 #define SUMO_DISPATCH(KERNEL, E, stream, args)                                                              \
   do {                                                                                                       \
     dim3 g_((E)->N), b_(WAVE);                                                                               \
     size_t lds_ = (size_t)(E)->L.total_bytes;                                                                \
-    switch ((E)->hm.nv) {                                                                                    \
-      case 28: hipLaunchKernelGGL(KERNEL<28>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
-      case 32: hipLaunchKernelGGL(KERNEL<32>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
-      case 36: hipLaunchKernelGGL(KERNEL<36>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
-      case 40: hipLaunchKernelGGL(KERNEL<40>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
-      case 44: hipLaunchKernelGGL(KERNEL<44>, g_, b_, lds_, stream, (E)->d_params, args); break;            \
-      default: FAIL(-19, "no kernel variant for nv=%d", (E)->hm.nv);                                        \
-    }                                                                                                        \
+    if (!for_kernel_variant((E)->hm.nv, [&](auto nvc_) {                                                     \
+          hipLaunchKernelGGL(KERNEL<decltype(nvc_)::value>, g_, b_, lds_, stream, (E)->d_params, args);      \
+        }))                                                                                                  \
+      FAIL(-19, "no kernel variant for nv=%d", (E)->hm.nv);                                                  \
   } while (0)
 
 static StepArgs base_args(sumo_engine* E) {
