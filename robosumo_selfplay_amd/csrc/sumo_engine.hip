@@ -48,7 +48,9 @@ struct Aux {  // derived integer tables (built on the host in build_aux)
       o_tri_i, o_tri_j;
   int o_wgmat;  // double table: 9 per geom (valid for world geoms)
   int o_stat_d, n_stat_d, o_stat_i, n_stat_i;  // tables copied into LDS at kernel start (see build_aux)
+  int o_wpa;                                   // double table: world geom positions [3*nworld] | axes [3*nworld]
   int nc, nworld;  // collision centres: bodies 0..nbody-1, then one per world geom
+  int nwp, wrounds, arounds;  // pairs with a static world geom (listed first), rounds of 64 for them / for the rest
 };
 
 struct Layout {  // LDS offsets in doubles unless noted
@@ -68,7 +70,7 @@ struct Layout {  // LDS offsets in doubles unless noted
   int cmask;     // per dof: 64-bit mask of the contacts whose Jacobian touches the dof
   int cond, Jb, cpar, cW, cp, jar, D, aref;
   int maxlim;    // capacity of limit rows (2 per hinge); D holds maxlim limit entries then one per contact
-  int stat_d;    // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wpos[3*nworld] | waxis[3*nworld]
+  int stat_d;    // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wlim[6*nworld]
   int i_base;  // start of int region (in doubles)
   // int region offsets (in ints, relative to int base)
   int con_b, lim_dof, lim_sign, limrow;  // limrow[dof] = first limit row | count << 8
@@ -104,7 +106,9 @@ struct StepArgs {
 #define MF(name) (mdl.fbase + mdl.o_##name)
 #define AI(name) (aux.ai + aux.o_##name)
 
-#define SYNC() __syncthreads()
+/* One wavefront per workgroup: LDS operations of a wave are issued and completed in order, so phases only need a
+ * compiler barrier between them (no s_waitcnt drain of unrelated loads, no s_barrier). */
+#define SYNC() asm volatile("" ::: "memory")
 
 // ---------------------------------------------------------------------------------------------------------
 // small math
@@ -162,9 +166,26 @@ __device__ __forceinline__ void mulmatTvec3(double* r, const double* m, const do
          z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
+// sin / cos to ~1 ulp for |x| < 1e4 (Cody-Waite reduction by pi/2 + the fdlibm kernel polynomials); the library routine,
+// whose argument reduction dominates its cost, only for larger arguments
+__device__ __forceinline__ void fast_sincos(double x, double* sn, double* cs) {
+  if (fabs(x) > 1e4) { sincos(x, sn, cs); return; }
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-fn, 1.57079632673412561417e+00, x);
+  r = fma(-fn, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  const double ps = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+  const double pc = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const int q = (int)fn & 3;
+  const double s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
 __device__ __forceinline__ void axisangle2quat(double* q, const double* axis, double angle) {
   double s, cs;
-  sincos(angle * 0.5, &s, &cs);
+  fast_sincos(angle * 0.5, &s, &cs);
   q[0] = cs; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
 __device__ __forceinline__ double dot6(const double* a, const double* b) {
@@ -259,7 +280,8 @@ __device__ __forceinline__ void sphere_box(Con1& c, double margin, const double*
   double t[3] = {sp[0] - bp[0], sp[1] - bp[1], sp[2] - bp[2]}, ctr[3], cl[3], dl[3];
   mulmatTvec3(ctr, bm, t);
   for (int k = 0; k < 3; k++) { cl[k] = ctr[k] > bs[k] ? bs[k] : (ctr[k] < -bs[k] ? -bs[k] : ctr[k]); dl[k] = cl[k] - ctr[k]; }
-  double dist = sqrt(dot3(dl, dl));
+  const double dd2 = dot3(dl, dl);
+  const double idist = dd2 > 0 ? fast_rsqrt(dd2) : 0.0, dist = dd2 * idist;
   c.ok = 0;
   if (dist - r > margin) return;
   double nl[3], pl[3];
@@ -274,7 +296,7 @@ __device__ __forceinline__ void sphere_box(Con1& c, double margin, const double*
     if (kb == 0) nl[0] = -sb; else if (kb == 1) nl[1] = -sb; else nl[2] = -sb;
     c.dist = -best - r;
   } else {
-    for (int k = 0; k < 3; k++) nl[k] = dl[k] / dist;
+    for (int k = 0; k < 3; k++) nl[k] = dl[k] * idist;
     c.dist = dist - r;
   }
   for (int k = 0; k < 3; k++) pl[k] = ctr[k] + nl[k] * (r + 0.5 * c.dist);
@@ -326,15 +348,14 @@ struct LaneRec {
 struct Params {  // lives in device memory; read through scalar / per-lane loads
   sumo_model_t mdl; Aux aux; Layout L;
   const LaneRec* lanes;     // [64]
-  const int* pair_rec;      // [PRmax*64]  c1 | c2<<8 | plane<<16 | valid<<17 | kind<<18 (see build_aux)
-  const float* pair_bound;  // conservative (rounded-up) bounding-sphere reach: margin + rbound1 + rbound2 (plane: margin + rbound2)
+  const int* pair_rec;      // [(wrounds + arounds) * 64] packed pair records (see build_aux)
+  const float* pair_bound;  // conservative (rounded-up) reach of each pair
 };
 
 template <int NV_>
 struct Ctx {
   static constexpr int NV = NV_;                                  // compile-time nv (register-resident factorisation)
   static constexpr int EPL = (NV_ * (NV_ + 1) / 2 + WAVE - 1) / WAVE;
-  static constexpr int PR = NV_ <= 28 ? 7 : NV_ <= 32 ? 10 : NV_ <= 36 ? 13 : NV_ <= 40 ? 17 : 21;  // rounds of 64 pairs
   Layout L;             // LDS layout, copied from Params once per launch (wave-uniform -> SGPRs)
   const LaneRec* kp;    // this lane's constant record (device memory, L1-resident); phases copy the fields they need
   const int* prp;       // this lane's packed pair records / bounds: element r*64
@@ -471,7 +492,8 @@ __device__ __forceinline__ void position_velocity(C& c) {
       double sx = wave_sum(ag == a ? px : 0.0), sy = wave_sum(ag == a ? py : 0.0), sz = wave_sum(ag == a ? pz : 0.0);
       if (lane == 0) {
         double stm = MF(body_subtreemass)[MI(agent_torso)[a]];
-        S(com)[3 * a] = sx / stm; S(com)[3 * a + 1] = sy / stm; S(com)[3 * a + 2] = sz / stm;
+        const double istm = fast_rcp(stm);
+        S(com)[3 * a] = sx * istm; S(com)[3 * a + 1] = sy * istm; S(com)[3 * a + 2] = sz * istm;
       }
     }
   }
@@ -616,12 +638,12 @@ __device__ __forceinline__ void mass_matrix(C& c) {
 #define CSIZE(ci) (c.sm + c.L.stat_d + 2 * (ci))
 #define CINVW(ci) (c.sm[c.L.stat_d + 2 * c.P->aux.nc + (ci)])
 #define WBOX(w) (c.sm + c.L.stat_d + 3 * c.P->aux.nc + 12 * (w))
+#define WLIM(w) (c.sm + c.L.stat_d + 3 * c.P->aux.nc + 12 * c.P->aux.nworld + 6 * (w))
 #define CHAINW(b) (c.si + c.L.stat_i + 2 * c.P->aux.nc + 2 * (b))
 #define CHLEN_AGENT(b) (c.si[c.L.stat_i + 2 * c.P->aux.nc + 2 * c.P->mdl.nbody + (b)])
 
 __device__ __forceinline__ void make_frame(double* f) {
-  double n2 = sqrt(f[3] * f[3] + f[4] * f[4] + f[5] * f[5]);
-  if (n2 < 0.5) {
+  if (f[3] * f[3] + f[4] * f[4] + f[5] * f[5] < 0.25) {
     f[3] = f[4] = f[5] = 0;
     if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
   }
@@ -634,50 +656,90 @@ __device__ __forceinline__ void make_frame(double* f) {
 template <class C>
 __device__ __forceinline__ void collision(C& c) {
   const int lane = c.lane, nb = c.P->mdl.nbody;
-  // survivors of the broad phase (pair order preserved): pair ids and packed centre records.  The queue borrows the
-  // constraint-row arrays (jar / aref), which are dead until make_constraint.
+  // survivors of the broad phase (pair order preserved): pair ids and packed centre records (c1 | c2 << 8).  The queue
+  // borrows the constraint-row arrays (jar / aref), which are dead until make_constraint.
   int* plist = (int*)S(jar);
   int* prlist = (int*)S(aref);
-  int ncand = 0, ncon = 0, dropped = 0;
-  const int* prp = launder_ptr(c.prp);
-  const float* pbp = launder_ptr(c.pbp);
+  int ncon = 0, dropped = 0;
+  const int WR = c.P->aux.wrounds, AR = c.P->aux.arounds, nwp = c.P->aux.nwp, maxcand = c.L.maxcand;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // The pair table lists the pairs with a static world geom first (WR rounds of 64, padded), then the pairs between
+  // moving geoms (AR rounds).  Rounds are tested four at a time, loads first, so their latencies overlap; a candidate
+  // with queue position in [base, base + maxcand) is stored, and the (rare) overflow is handled by running the tests
+  // again for the next window.
+  int base = 0, total = 0;
+  do {
+    int run = 0;
+    const int* prp = launder_ptr(c.prp);
+    const float* pbp = launder_ptr(c.pbp);
+    // ---- world pairs: distance from the moving geom's centre to the static geom's extent (box / segment / half space)
+    for (int r0 = 0; r0 < WR; r0 += 4) {
+      int rec[4], pass[4];
 #pragma unroll
-  for (int r = 0; r < C::PR; r++) {
-    const int rec = prp[WAVE * r];
-    int pass = 0;
-    if (rec & (1 << 17)) {
-      const int c1 = rec & 0xFF, c2 = (rec >> 8) & 0xFF, kind = (rec >> 18) & 3;
-      const double* p1 = S(xipos) + 3 * c1;
-      const double* p2 = S(xipos) + 3 * c2;
-      const double bound = (double)pbp[WAVE * r];
-      double t[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-      if (rec & (1 << 16)) pass = !(dot3(t, S(gaxis) + 3 * c1) > bound);
-      else {
-        double d2;
-        if (kind == 1) {         // c2 is a static box: exact distance from the other geom's centre to the box
-          const double* bm = WBOX(c2 - nb);
-          double ctr[3];
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + q;
+        rec[q] = 0; pass[q] = 0;
+        if (r < WR) {
+          rec[q] = prp[WAVE * r];
+          const double bound = (double)pbp[WAVE * r];
+          const int ca = rec[q] & 0xFF, cw = (rec[q] >> 8) & 0xFF, w = cw >= nb ? cw - nb : 0;
+          const double* pa = S(xipos) + 3 * ca;
+          const double* pw = S(xipos) + 3 * cw;
+          const double* bm = WBOX(w);
+          const double* wl = WLIM(w);
+          const double t[3] = {pa[0] - pw[0], pa[1] - pw[1], pa[2] - pw[2]};
+          double ctr[3], d2 = 0;
           mulmatTvec3(ctr, bm, t);
-          d2 = 0;
-          for (int k = 0; k < 3; k++) { double e = fabs(ctr[k]) - bm[9 + k]; if (e > 0) d2 += e * e; }
-        } else if (kind >= 2) {  // one side is a static capsule (border rod): distance from the other centre to its axis segment
-          const int w = kind == 2 ? c1 : c2;
-          const double* g = S(gaxis) + 3 * w;
-          const double hl = CSIZE(w)[1];
-          double x = dot3(t, g);
-          x = x > hl ? hl : (x < -hl ? -hl : x);
-          // (kind 2: t points from the rod centre to the other geom; kind 3: the opposite -- only |t - g x|^2 matters)
-          double d[3] = {t[0] - g[0] * x, t[1] - g[1] * x, t[2] - g[2] * x};
-          d2 = dot3(d, d);
-        } else d2 = dot3(t, t);
-        pass = !(d2 > bound * bound);
+#pragma unroll
+          for (int k = 0; k < 3; k++) { double e = fmax(fmax(ctr[k] - wl[k], wl[3 + k] - ctr[k]), 0.0); d2 += e * e; }
+          pass[q] = ((rec[q] >> 17) & 1) && !(d2 > bound * bound);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + q;
+        if (r < WR) {
+          const unsigned long long bal = __ballot(pass[q]);
+          const int pos = run + __popcll(bal & lt_mask) - base;
+          if (pass[q] && pos >= 0 && pos < maxcand) {
+            const int ca = rec[q] & 0xFF, cw = (rec[q] >> 8) & 0xFF;
+            plist[pos] = lane + WAVE * r;
+            prlist[pos] = (rec[q] & (1 << 16)) ? (cw | (ca << 8)) : (ca | (cw << 8));   // bit 16: the world geom is geom1
+          }
+          run += __popcll(bal);
+        }
       }
     }
-    unsigned long long bal = __ballot(pass);
-    int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
-    if (pass) { plist[pos] = lane + WAVE * r; prlist[pos] = rec; }
-    ncand += __popcll(bal);
-    if (ncand + WAVE <= c.L.maxcand && r + 1 < C::PR) continue;
+    // ---- pairs of moving geoms: bounding spheres
+    prp += WAVE * WR; pbp += WAVE * WR;
+    for (int r0 = 0; r0 < AR; r0 += 4) {
+      int rec[4], pass[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + q;
+        rec[q] = 0; pass[q] = 0;
+        if (r < AR) {
+          rec[q] = prp[WAVE * r];
+          const double bound = (double)pbp[WAVE * r];
+          const double* p1 = S(xipos) + 3 * (rec[q] & 0xFF);
+          const double* p2 = S(xipos) + 3 * ((rec[q] >> 8) & 0xFF);
+          const double t[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+          pass[q] = ((rec[q] >> 17) & 1) && !(dot3(t, t) > bound * bound);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + q;
+        if (r < AR) {
+          const unsigned long long bal = __ballot(pass[q]);
+          const int pos = run + __popcll(bal & lt_mask) - base;
+          if (pass[q] && pos >= 0 && pos < maxcand) { plist[pos] = nwp + lane + WAVE * r; prlist[pos] = rec[q] & 0xFFFF; }
+          run += __popcll(bal);
+        }
+      }
+    }
+    total = run;
+    const int ncand = total - base < maxcand ? total - base : maxcand;
     SYNC();
     PROF(4);
     for (int k0 = 0; k0 < ncand; k0 += WAVE) {
@@ -724,11 +786,12 @@ __device__ __forceinline__ void collision(C& c) {
           double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
           double det = ma * mc - mb * mb, v1[3], v2[3];
           if (fabs(det) >= MINVAL) {
-            double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
-            if (x1 > 1) { x1 = 1; x2 = (v - mb) / mc; }
-            else if (x1 < -1) { x1 = -1; x2 = (v + mb) / mc; }
-            if (x2 > 1) { x2 = 1; x1 = (u - mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
-            else if (x2 < -1) { x2 = -1; x1 = (u + mb) / ma; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
+            const double idet = fast_rcp(det), imc = fast_rcp(mc), ima = fast_rcp(ma);
+            double x1 = (mc * u - mb * v) * idet, x2 = (ma * v - mb * u) * idet;
+            if (x1 > 1) { x1 = 1; x2 = (v - mb) * imc; }
+            else if (x1 < -1) { x1 = -1; x2 = (v + mb) * imc; }
+            if (x2 > 1) { x2 = 1; x1 = (u - mb) * ima; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
+            else if (x2 < -1) { x2 = -1; x1 = (u + mb) * ima; if (x1 > 1) x1 = 1; else if (x1 < -1) x1 = -1; }
             for (int q = 0; q < 3; q++) { v1[q] = p1[q] + a1[q] * x1; v2[q] = p2[q] + a2[q] * x2; }
             sphere_sphere(cs[0], margin, v1, s1[0], v2, s2[0]);
           } else {
@@ -771,7 +834,7 @@ __device__ __forceinline__ void collision(C& c) {
                   }
                 }
               }
-              double ts = lo - glo * (hi - lo) / (ghi - glo);
+              double ts = lo - glo * (hi - lo) * fast_rcp(ghi - glo);
               for (int q = 0; q < 3; q++) e[q] = p1[q] + ts * axw[q];
               sphere_box(cs[2], margin, e, s1[0], p2, bm, bs);
             }
@@ -781,8 +844,8 @@ __device__ __forceinline__ void collision(C& c) {
       int act[3], n = 0;
 #pragma unroll
       for (int q = 0; q < 3; q++) { act[q] = cs[q].ok && (cs[q].dist < margin); n += act[q]; }
-      int total, base = wave_excl_scan(n, lane, &total);
-      int slot = ncon + base;
+      int ctot, cbase = wave_excl_scan(n, lane, &ctot);
+      int slot = ncon + cbase;
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         if (act[q]) {
@@ -799,12 +862,12 @@ __device__ __forceinline__ void collision(C& c) {
           slot++;
         }
       }
-      ncon += total;
+      ncon += ctot;
     }
-    ncand = 0;
     SYNC();
     PROF(5);
-  }
+    base += maxcand;
+  } while (base < total);
   if (ncon > c.L.maxcon) { dropped = ncon - c.L.maxcon; ncon = c.L.maxcon; }
   c.ncon = ncon;
   c.ndropped = dropped;
@@ -823,11 +886,11 @@ __device__ __forceinline__ double impedance(const double* solimp, double x) {
   if (width < MINVAL) width = MINVAL;
   mid = fmin(fmax(mid, 0.0001), 0.9999);
   if (power < 1) power = 1;
-  double xx = fabs(x) / width, y;
+  double xx = fabs(x) * fast_rcp(width), y;
   if (xx >= 1) return dmax;
   if (xx <= 0) return dmin;
   if (power == 1) y = xx;
-  else if (power == 2) y = xx <= mid ? xx * xx / mid : 1 - (1 - xx) * (1 - xx) / (1 - mid);  // MuJoCo default solimp
+  else if (power == 2) y = xx <= mid ? xx * xx * fast_rcp(mid) : 1 - (1 - xx) * (1 - xx) * fast_rcp(1 - mid);  // MuJoCo default solimp
   else y = impedance_general_pow(xx, mid, power);
   return dmin + y * (dmax - dmin);
 }
@@ -838,10 +901,10 @@ __device__ __forceinline__ double row_params(double timestep, const double* solr
   if (tc < 2 * timestep) tc = 2 * timestep;
   double imp = impedance(solimp, pos - margin);
   double kk = dmax * dmax * tc * tc * dr * dr, bb = dmax * tc;
-  double K = 1.0 / (kk < MINVAL ? MINVAL : kk);
-  *B = 2.0 / (bb < MINVAL ? MINVAL : bb);
+  double K = fast_rcp(kk < MINVAL ? MINVAL : kk);
+  *B = 2.0 * fast_rcp(bb < MINVAL ? MINVAL : bb);
   *kterm = K * imp * (pos - margin);
-  double R = (1 - imp) * diag / imp;
+  double R = (1 - imp) * diag * fast_rcp(imp);
   return R < MINVAL ? MINVAL : R;
 }
 
@@ -887,11 +950,11 @@ __device__ __forceinline__ void make_constraint(C& c) {
     double diag = K.jt_invw;
     if (act_lo) {
       double B, kt, R = row_params(timestep, def_solref, def_solimp, dlo, jm, diag, &B, &kt);
-      lim_dof[r] = dof; lim_sign[r] = 1.0; S(D)[r] = 1.0 / R; S(aref)[r] = B; S(jar)[r] = kt; r++;
+      lim_dof[r] = dof; lim_sign[r] = 1.0; S(D)[r] = fast_rcp(R); S(aref)[r] = B; S(jar)[r] = kt; r++;
     }
     if (act_hi) {
       double B, kt, R = row_params(timestep, def_solref, def_solimp, dhi, jm, diag, &B, &kt);
-      lim_dof[r] = dof; lim_sign[r] = -1.0; S(D)[r] = 1.0 / R; S(aref)[r] = B; S(jar)[r] = kt; r++;
+      lim_dof[r] = dof; lim_sign[r] = -1.0; S(D)[r] = fast_rcp(R); S(aref)[r] = B; S(jar)[r] = kt; r++;
     }
   }
   c.nlim = nlim;
@@ -920,7 +983,7 @@ __device__ __forceinline__ void make_constraint(C& c) {
     double Rpy = 2 * mu * mu * R;
     if (Rpy < MINVAL) Rpy = MINVAL;
     S(cpar)[ci] = mu;
-    S(D)[c.L.maxlim + ci] = 1.0 / Rpy;   // one D per contact (its four pyramid rows share it)
+    S(D)[c.L.maxlim + ci] = fast_rcp(Rpy);   // one D per contact (its four pyramid rows share it)
     for (int k = 0; k < 4; k++) { int r = nlim + 4 * ci + k; S(aref)[r] = B; S(jar)[r] = kt; }
   }
   PROF(6);
@@ -1660,7 +1723,7 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   for (int i = c.lane; i < P->aux.n_stat_i; i += WAVE) c.si[P->L.stat_i + i] = P->aux.ai[P->aux.o_stat_i + i];
   {
     const int nb = P->mdl.nbody, nw = P->aux.nworld, nc = P->aux.nc;
-    const double* wpos = P->aux.af + P->aux.o_stat_d + 3 * nc + 12 * nw;
+    const double* wpos = P->aux.af + P->aux.o_wpa;
     for (int i = c.lane; i < 3 * nw; i += WAVE) { smem[P->L.xipos + 3 * nb + i] = wpos[i]; smem[P->L.gaxis + 3 * nb + i] = wpos[3 * nw + i]; }
   }
   __syncthreads();
@@ -1955,16 +2018,17 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
     int ci = gbody[g] == 0 ? nb + (g - SUMO_I(m, body_geomadr)[0]) : gbody[g];
     cen_of_geom[g] = ci; geom_of_cen[ci] = g;
   }
-  // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wpos[3*nworld] | waxis[3*nworld]
+  // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wlim[6*nworld]
   A.o_stat_d = (int)af.size();
   {
-    std::vector<double> sd((size_t)3 * nc + 18 * nworld, 0.0);
+    std::vector<double> sd((size_t)3 * nc + 18 * nworld, 0.0), wpa((size_t)6 * nworld, 0.0);
     for (int ci = 0; ci < nc; ci++) {
       int g = geom_of_cen[ci];
       if (g >= 0) { sd[2 * ci] = SUMO_F(m, geom_size)[3 * g]; sd[2 * ci + 1] = SUMO_F(m, geom_size)[3 * g + 1]; }
       int body = ci < nb ? ci : 0;
       sd[2 * nc + ci] = SUMO_F(m, body_invweight0)[2 * body];
     }
+    const double BIG = 1e300;
     for (int w = 0; w < nworld; w++) {
       int g = SUMO_I(m, body_geomadr)[0] + w;
       double R[9];
@@ -1972,11 +2036,21 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
       double* wb = &sd[3 * nc + 12 * w];
       for (int k = 0; k < 9; k++) wb[k] = R[k];
       for (int k = 0; k < 3; k++) wb[9 + k] = SUMO_F(m, geom_size)[3 * g + k];
-      for (int k = 0; k < 3; k++) sd[3 * nc + 12 * nworld + 3 * w + k] = SUMO_F(m, geom_pos)[3 * g + k];
-      sd[3 * nc + 15 * nworld + 3 * w + 0] = R[2]; sd[3 * nc + 15 * nworld + 3 * w + 1] = R[5]; sd[3 * nc + 15 * nworld + 3 * w + 2] = R[8];
+      // broad-phase extent of the geom in its own frame, hi[3] | lo[3] (the other geom's bounding radius goes into the
+      // pair bound): box = its half sizes; capsule / border rod = its axis segment; plane = the half space z <= 0;
+      // anything else = its centre with the bounding radius
+      double* wl = &sd[3 * nc + 12 * nworld + 6 * w];
+      const double* gs = SUMO_F(m, geom_size) + 3 * g;
+      if (gtype[g] == SUMO_GEOM_BOX) { for (int k = 0; k < 3; k++) { wl[k] = gs[k]; wl[3 + k] = -gs[k]; } }
+      else if (gtype[g] == SUMO_GEOM_CAPSULE || gtype[g] == SUMO_GEOM_CYLINDER) { wl[2] = gs[1]; wl[5] = -gs[1]; }
+      else if (gtype[g] == SUMO_GEOM_PLANE) { wl[0] = wl[1] = BIG; wl[2] = 0; wl[3] = wl[4] = wl[5] = -BIG; }
+      for (int k = 0; k < 3; k++) wpa[3 * w + k] = SUMO_F(m, geom_pos)[3 * g + k];
+      wpa[3 * nworld + 3 * w + 0] = R[2]; wpa[3 * nworld + 3 * w + 1] = R[5]; wpa[3 * nworld + 3 * w + 2] = R[8];
     }
     A.n_stat_d = (int)sd.size();
     af.insert(af.end(), sd.begin(), sd.end());
+    A.o_wpa = (int)af.size();   // world geom positions / axes: read once per launch, not kept in LDS
+    af.insert(af.end(), wpa.begin(), wpa.end());
   }
   // static int tables: ctype[nc] | cbody[nc] | chain words [2*nb] | chlen_agent[nb]
   {
@@ -2054,33 +2128,43 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
       K.a_lo = SUMO_F(m, actuator_ctrlrange)[2 * l]; K.a_hi = SUMO_F(m, actuator_ctrlrange)[2 * l + 1];
     }
   }
-  // ---- packed pair records for the broad phase
+  // ---- packed pair records for the broad phase: pairs with a static world geom first (the model lists them first:
+  // body-pair order, world body = 0), padded to whole rounds of 64, then the pairs between moving geoms.
+  //   world pair:  moving centre | world centre << 8 | (world geom is geom1) << 16 | valid << 17
+  //                bound = margin + rbound(moving geom) [+ radius of a static capsule; + rbound of other static shapes]
+  //   moving pair: c1 | c2 << 8 | valid << 17;  bound = margin + rbound1 + rbound2
+  // bounds are rounded up in float: the broad phase may only over-include
   {
-    int PR = nv <= 28 ? 7 : nv <= 32 ? 10 : nv <= 36 ? 13 : nv <= 40 ? 17 : 21;
-    if (m->npair > PR * WAVE) FAIL(-23, "%d collision pairs exceed the %d the nv=%d kernel variant holds", m->npair, PR * WAVE, nv);
-    E->pair_rec.assign((size_t)PR * WAVE, 0);
-    E->pair_bound.assign((size_t)PR * WAVE, 0.0f);
+    int nwp = 0;
+    while (nwp < m->npair && (gbody[SUMO_I(m, pair_geom1)[nwp]] == 0 || gbody[SUMO_I(m, pair_geom2)[nwp]] == 0)) nwp++;
+    for (int p = nwp; p < m->npair; p++)
+      if (gbody[SUMO_I(m, pair_geom1)[p]] == 0 || gbody[SUMO_I(m, pair_geom2)[p]] == 0)
+        FAIL(-23, "collision pair %d: pairs with a world geom must precede the others", p);
+    const int WR = (nwp + WAVE - 1) / WAVE, AR = (m->npair - nwp + WAVE - 1) / WAVE;
+    A.nwp = nwp; A.wrounds = WR; A.arounds = AR;
+    E->pair_rec.assign((size_t)(WR + AR) * WAVE, 0);
+    E->pair_bound.assign((size_t)(WR + AR) * WAVE, 0.0f);
+    auto up = [](double bound) {
+      float bf = (float)bound;
+      while ((double)bf < bound) bf = nextafterf(bf, INFINITY);
+      return nextafterf(bf, INFINITY);
+    };
     for (int p = 0; p < m->npair; p++) {
       int g1 = SUMO_I(m, pair_geom1)[p], g2 = SUMO_I(m, pair_geom2)[p];
-      int plane = gtype[g1] == SUMO_GEOM_PLANE;
-      // static world geoms get a tighter test than bounding spheres: exact point-box distance for boxes (kind 1), distance
-      // to the axis segment for capsules / the border rods (kind 2: geom1 is the static capsule, 3: geom2)
-      const int* gbody = SUMO_I(m, geom_bodyid);
-      auto is_cap = [&](int g) { return gtype[g] == SUMO_GEOM_CAPSULE || gtype[g] == SUMO_GEOM_CYLINDER; };
-      int kind = 0;
-      double bound = SUMO_F(m, pair_margin)[p] + SUMO_F(m, geom_rbound)[g2] + (plane ? 0.0 : SUMO_F(m, geom_rbound)[g1]);
-      if (!plane && gbody[g2] == 0 && gtype[g2] == SUMO_GEOM_BOX && gbody[g1] != 0) {
-        kind = 1; bound = SUMO_F(m, pair_margin)[p] + SUMO_F(m, geom_rbound)[g1];
-      } else if (!plane && gbody[g1] == 0 && is_cap(g1) && gbody[g2] != 0) {
-        kind = 2; bound = SUMO_F(m, pair_margin)[p] + SUMO_F(m, geom_rbound)[g2] + SUMO_F(m, geom_size)[3 * g1];
-      } else if (!plane && gbody[g2] == 0 && is_cap(g2) && gbody[g1] != 0) {
-        kind = 3; bound = SUMO_F(m, pair_margin)[p] + SUMO_F(m, geom_rbound)[g1] + SUMO_F(m, geom_size)[3 * g2];
+      const double margin = SUMO_F(m, pair_margin)[p];
+      if (p < nwp) {
+        if (gbody[g1] == 0 && gbody[g2] == 0) continue;   // static-static: never collides (slot stays invalid)
+        const int w1 = gbody[g1] == 0, gw = w1 ? g1 : g2, ga = w1 ? g2 : g1, tw = gtype[gw];
+        double bound = margin + SUMO_F(m, geom_rbound)[ga];
+        if (tw == SUMO_GEOM_CAPSULE || tw == SUMO_GEOM_CYLINDER) bound += SUMO_F(m, geom_size)[3 * gw];
+        else if (tw != SUMO_GEOM_BOX && tw != SUMO_GEOM_PLANE) bound += SUMO_F(m, geom_rbound)[gw];
+        E->pair_rec[p] = cen_of_geom[ga] | (cen_of_geom[gw] << 8) | (w1 << 16) | (1 << 17);
+        E->pair_bound[p] = up(bound);
+      } else {
+        const int sl = WR * WAVE + (p - nwp);
+        E->pair_rec[sl] = cen_of_geom[g1] | (cen_of_geom[g2] << 8) | (1 << 17);
+        E->pair_bound[sl] = up(margin + SUMO_F(m, geom_rbound)[g1] + SUMO_F(m, geom_rbound)[g2]);
       }
-      float bf = (float)bound;
-      while ((double)bf < bound) bf = nextafterf(bf, INFINITY);   // conservative: the broad phase may only over-include
-      bf = nextafterf(bf, INFINITY);
-      E->pair_rec[p] = cen_of_geom[g1] | (cen_of_geom[g2] << 8) | (plane << 16) | (1 << 17) | (kind << 18);
-      E->pair_bound[p] = bf;
     }
   }
   return 0;
