@@ -69,11 +69,11 @@ struct Layout {  // LDS offsets in doubles unless noted
   int stash;     // 4 doubles parked across the step loop
   int cmask;     // per dof: 64-bit mask of the contacts whose Jacobian touches the dof
   int cond, Jb, cpar, cW, cp, jar, D, aref;
-  int maxlim;    // capacity of limit rows (2 per hinge); D holds maxlim limit entries then one per contact
+  int limD, limA;  // joint-limit slots, dof-indexed: [nv] lower side | [nv] upper side (D = 0: side not active)
   int stat_d;    // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wlim[6*nworld]
   int i_base;  // start of int region (in doubles)
   // int region offsets (in ints, relative to int base)
-  int con_b, lim_dof, lim_sign, limrow;  // limrow[dof] = first limit row | count << 8
+  int con_b;
   int b_dofidx;  // byte offset (relative to int base): signed char [16 * maxcon], dof of each Jacobian slot or -1
   int stat_i;    // static int tables: ctype[nc] | cbody[nc] | chain[2*nbody] | chlen_agent[nbody]
   int b_slotof;  // byte offset (relative to int base, in bytes)
@@ -386,8 +386,6 @@ __device__ __forceinline__ const T* launder_ptr(const T* p) { asm volatile("" : 
 // mass matrix element (i, j) of the block-diagonal storage; valid when i and j belong to the same agent tree
 #define MIDX(i, j) ((i) * c.L.mld + ((j) >= c.L.d1 ? (j) - c.L.d1 : (j)))
 #define SAME_TREE(i, j) (((i) >= c.L.d1) == ((j) >= c.L.d1))
-// D of constraint row r: limit rows store their own, the four rows of a contact share one
-#define ROWD(r) ((r) < c.nlim ? S(D)[r] : S(D)[c.L.maxlim + (((r) - c.nlim) >> 2)])
 #define HP(i, k) ((i) * ((i) + 1) / 2 + (k))  /* packed lower-triangular index, i >= k */
 #ifdef SUMO_PROFILE
 #define PROF(k) do { long long _t = clock64(); c.prof[k] += (unsigned long long)(_t - c.tprev); c.tprev = _t; } while (0)
@@ -928,35 +926,29 @@ __device__ __forceinline__ void make_constraint(C& c) {
   const double timestep = MF(opt)[SUMO_OPT_TIMESTEP];
   const double def_solref[2] = {0.02, 1.0};
   const double def_solimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
-  int* lim_dof = c.si + c.L.lim_dof;
-  double* lim_sign = (double*)(c.si + c.L.lim_sign);
-  // joint limits (lower side first, then upper, joints in order); lane == joint id
-  int nact = 0, act_lo = 0, act_hi = 0;
-  double dlo = 0, dhi = 0;
-  const double jm = K.jt_margin;
-  if (lane < mdl.njnt && K.jt_type == SUMO_JNT_HINGE && K.jt_limited) {
-    double value = S(qpos)[K.jt_qadr];
-    dlo = value - K.jt_lo;
-    dhi = K.jt_hi - value;
-    act_lo = dlo < jm; act_hi = dhi < jm;
-    nact = act_lo + act_hi;
-  }
-  int nlim, base = wave_excl_scan(nact, lane, &nlim);
-  if (lane < nv) { (c.si + c.L.limrow)[lane] = 0; ((unsigned long long*)S(cmask))[lane] = 0ull; }
-  SYNC();
-  if (nact) {
-    int dof = K.jt_dadr, r = base;
-    (c.si + c.L.limrow)[dof] = base | (nact << 8);
-    double diag = K.jt_invw;
+  // joint limits; lane == joint id.  A hinge owns two fixed slots indexed by its dof (lower side, upper side): D = 1/R and
+  // aref, with D = 0 when the side is not active (every term of the solver carries D, so absent rows cost nothing).
+  // The Jacobian of a limit row is +-e_dof: the dof's own lane evaluates its rows without touching LDS row arrays.
+  int act_lo = 0, act_hi = 0;
+  if (lane < nv) ((unsigned long long*)S(cmask))[lane] = 0ull;
+  if (lane < mdl.njnt && K.jt_type == SUMO_JNT_HINGE) {
+    const int dof = K.jt_dadr;
+    const double jm = K.jt_margin, value = S(qpos)[K.jt_qadr], vel = S(qvel)[dof];
+    const double dlo = value - K.jt_lo, dhi = K.jt_hi - value;
+    act_lo = K.jt_limited && dlo < jm; act_hi = K.jt_limited && dhi < jm;
+    double D0 = 0, A0 = 0, D1 = 0, A1 = 0;
     if (act_lo) {
-      double B, kt, R = row_params(timestep, def_solref, def_solimp, dlo, jm, diag, &B, &kt);
-      lim_dof[r] = dof; lim_sign[r] = 1.0; S(D)[r] = fast_rcp(R); S(aref)[r] = B; S(jar)[r] = kt; r++;
+      double B, kt, R = row_params(timestep, def_solref, def_solimp, dlo, jm, K.jt_invw, &B, &kt);
+      D0 = fast_rcp(R); A0 = -B * vel - kt;
     }
     if (act_hi) {
-      double B, kt, R = row_params(timestep, def_solref, def_solimp, dhi, jm, diag, &B, &kt);
-      lim_dof[r] = dof; lim_sign[r] = -1.0; S(D)[r] = fast_rcp(R); S(aref)[r] = B; S(jar)[r] = kt; r++;
+      double B, kt, R = row_params(timestep, def_solref, def_solimp, dhi, jm, K.jt_invw, &B, &kt);
+      D1 = fast_rcp(R); A1 = B * vel - kt;     // row = -e_dof: efc_vel = -qvel
     }
+    S(limD)[dof] = D0; S(limD)[nv + dof] = D1; S(limA)[dof] = A0; S(limA)[nv + dof] = A1;
   }
+  const int nlim = __popcll(__ballot(act_lo)) + __popcll(__ballot(act_hi));
+  SYNC();
   c.nlim = nlim;
   c.nefc = nlim + 4 * ncon;
   {
@@ -983,8 +975,8 @@ __device__ __forceinline__ void make_constraint(C& c) {
     double Rpy = 2 * mu * mu * R;
     if (Rpy < MINVAL) Rpy = MINVAL;
     S(cpar)[ci] = mu;
-    S(D)[c.L.maxlim + ci] = fast_rcp(Rpy);   // one D per contact (its four pyramid rows share it)
-    for (int k = 0; k < 4; k++) { int r = nlim + 4 * ci + k; S(aref)[r] = B; S(jar)[r] = kt; }
+    S(D)[ci] = fast_rcp(Rpy);   // one D per contact (its four pyramid rows share it)
+    for (int k = 0; k < 4; k++) { int r = 4 * ci + k; S(aref)[r] = B; S(jar)[r] = kt; }
   }
   PROF(6);
   // slot map init
@@ -1057,14 +1049,23 @@ __device__ __forceinline__ void contact_Jx(C& c, const double* x) {
   }
   SYNC();
 }
-// value of row r of J*x given cp (after contact_Jx)
+// value of contact row r (= 4 * contact + pyramid edge) of J*x given cp (after contact_Jx)
 template <class C>
-__device__ __forceinline__ double row_Jx(const C& c, int r, const double* x) {
-  if (r < c.nlim) return ((const double*)(c.si + c.L.lim_sign))[r] * x[(c.si + c.L.lim_dof)[r]];
-  int q = r - c.nlim, ci = q >> 2, k = q & 3;
+__device__ __forceinline__ double row_Jx(const C& c, int r) {
+  const int ci = r >> 2, k = r & 3;
   double mu = c.sm[c.L.cpar + ci];
   const double* cp = c.sm + c.L.cp + 3 * ci;
   return cp[0] + ((k & 1) ? -mu : mu) * cp[1 + (k >> 1)];
+}
+// this lane's two joint-limit slots (lower, upper): D (0 = absent) and aref
+struct LimRows { double D0, D1, A0, A1; };
+template <class C>
+__device__ __forceinline__ LimRows lim_rows(const C& c) {
+  const int nv = c.P->mdl.nv, li = c.lane < nv ? c.lane : 0;
+  LimRows q;
+  q.D0 = c.sm[c.L.limD + li]; q.D1 = c.sm[c.L.limD + nv + li]; q.A0 = c.sm[c.L.limA + li]; q.A1 = c.sm[c.L.limA + nv + li];
+  if (c.lane >= nv) q.D0 = q.D1 = 0.0;
+  return q;
 }
 
 // y_i = sum_k M[i][k] x[k]   (x in LDS); M is block diagonal, so only the lane's own tree contributes
@@ -1285,13 +1286,18 @@ __device__ __forceinline__ double tree_factor_solve(C& c, const double (&row)[8]
   return act ? x : 0.0;
 }
 
-// cost(x) = 1/2 (Ma - qfrc_smooth).(x - qacc_smooth) + sum_active 1/2 D jar^2
+// cost(x) = 1/2 (Ma - qfrc_smooth).(x - qacc_smooth) + sum_active 1/2 D jar^2   (jar of the contact rows in LDS; the
+// limit rows of a dof are evaluated by its lane: jar = +-x - aref)
 template <class C>
 __device__ __forceinline__ double solver_cost(C& c, double Ma_i, double x_i) {
   const int lane = c.lane, nv = c.P->mdl.nv;
   double v = 0;
   if (lane < nv) v = 0.5 * (Ma_i - S(qsm)[lane]) * (x_i - S(asmo)[lane]);
-  for (int r = lane; r < c.nefc; r += WAVE) { double j = S(jar)[r]; if (j < 0) v += 0.5 * ROWD(r) * j * j; }
+  const LimRows q = lim_rows(c);
+  const double j0 = x_i - q.A0, j1 = -x_i - q.A1;
+  if (j0 < 0) v += 0.5 * q.D0 * j0 * j0;
+  if (j1 < 0) v += 0.5 * q.D1 * j1 * j1;
+  for (int r = lane; r < 4 * c.ncon; r += WAVE) { double j = S(jar)[r]; if (j < 0) v += 0.5 * S(D)[r >> 2] * j * j; }
   return wave_sum(v);
 }
 
@@ -1299,7 +1305,7 @@ template <class C>
 __device__ __forceinline__ void newton_solve(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const Aux& aux = c.P->aux;
-  const int lane = c.lane, nv = mdl.nv, ld = c.L.ld, nefc = c.nefc, ncon = c.ncon, nlim = c.nlim;
+  const int lane = c.lane, nv = mdl.nv, nefc = c.nefc, ncon = c.ncon, nrow = 4 * c.ncon;
   const double tol = MF(opt)[SUMO_OPT_TOLERANCE];
   const int maxiter = (int)MF(opt)[SUMO_OPT_ITERATIONS];
   const double scale = 1.0 / (MF(opt)[SUMO_OPT_MEANINERTIA] * (nv > 1 ? nv : 1));
@@ -1310,33 +1316,39 @@ __device__ __forceinline__ void newton_solve(C& c) {
     return;
   }
   const unsigned char* slotof = c.sb + c.L.b_slotof;
+  constexpr int RPL = C::NV <= 36 ? 2 : 3;   // contact rows per lane: 4 * maxcon <= 64 * RPL (build_layout)
   // ---- warm start: better of qacc_warmstart (or, in warm_mode 1, the previous RK stage's qacc still held in x) and
   // qacc_smooth
   if (!c.use_prev && lane < nv) x[lane] = S(warm)[lane];
   SYNC();
   double Ma = dense_Mx(c, x);
   contact_Jx(c, x);
-  for (int r = lane; r < nefc; r += WAVE) S(jar)[r] = row_Jx(c, r, x) - S(aref)[r];
+  for (int r = lane; r < nrow; r += WAVE) S(jar)[r] = row_Jx(c, r) - S(aref)[r];
   SYNC();
   double xi = lane < nv ? x[lane] : 0.0;
   double cost_ws = solver_cost(c, Ma, xi);
   contact_Jx(c, S(asmo));
-  constexpr int RPLW = C::NV <= 28 ? 2 : 4;   // rows per lane (see the line search)
-  double jsm[RPLW];
+  double jsm[RPL];
   double csm = 0;
+  {
+    const LimRows q = lim_rows(c);
+    const double xs = lane < nv ? S(asmo)[lane] : 0.0, j0 = xs - q.A0, j1 = -xs - q.A1;
+    if (j0 < 0) csm += 0.5 * q.D0 * j0 * j0;
+    if (j1 < 0) csm += 0.5 * q.D1 * j1 * j1;
+  }
 #pragma unroll
-  for (int q = 0; q < RPLW; q++) {
+  for (int q = 0; q < RPL; q++) {
     int r = lane + WAVE * q;
-    double jv = r < nefc ? row_Jx(c, r, S(asmo)) - S(aref)[r] : 1.0;
+    double jv = r < nrow ? row_Jx(c, r) - S(aref)[r] : 1.0;
     jsm[q] = jv;
-    if (jv < 0) csm += 0.5 * ROWD(r) * jv * jv;
+    if (jv < 0) csm += 0.5 * S(D)[r >> 2] * jv * jv;
   }
   double cost_sm = wave_sum(csm);
   double cost = cost_ws;
   if (cost_ws > cost_sm) {
     if (lane < nv) { xi = S(asmo)[lane]; x[lane] = xi; }
 #pragma unroll
-    for (int q = 0; q < RPLW; q++) { int r = lane + WAVE * q; if (r < nefc) S(jar)[r] = jsm[q]; }
+    for (int q = 0; q < RPL; q++) { int r = lane + WAVE * q; if (r < nrow) S(jar)[r] = jsm[q]; }
     SYNC();
     Ma = dense_Mx(c, x);
     cost = solver_cost(c, Ma, xi);
@@ -1348,9 +1360,9 @@ __device__ __forceinline__ void newton_solve(C& c) {
     // ---- per-contact force / weight summaries of the active set
     for (int ci = lane; ci < ncon; ci += WAVE) {
       double mu = S(cpar)[ci], f[4], dact[4];
+      const double Dr = S(D)[ci];
       for (int k = 0; k < 4; k++) {
-        int r = nlim + 4 * ci + k;
-        double j = S(jar)[r], Dr = S(D)[c.L.maxlim + ci];
+        double j = S(jar)[4 * ci + k];
         dact[k] = j < 0 ? Dr : 0.0;
         f[k] = j < 0 ? -Dr * j : 0.0;
       }
@@ -1366,17 +1378,14 @@ __device__ __forceinline__ void newton_solve(C& c) {
       W[4] = mu * mu * (dact[2] + dact[3]);
     }
     SYNC();
-    // ---- gradient (dof-major gather of J^T f) and limit-row diagonal
-    double g = 0;
+    // ---- gradient: own limit rows (lane-local) + dof-major gather of J^T f over the contacts touching the dof
+    double g = 0, dl = 0;
+    const LimRows lq = lim_rows(c);
     if (lane < nv) {
-      double qc = 0, dl = 0;
-      const double* lim_sign = (const double*)(c.si + c.L.lim_sign);
-      const int lr = (c.si + c.L.limrow)[lane];
-      for (int q = 0; q < (lr >> 8); q++) {
-        int r = (lr & 0xFF) + q;
-        double j = S(jar)[r];
-        if (j < 0) { qc += lim_sign[r] * (-S(D)[r] * j); dl += S(D)[r]; }
-      }
+      double qc = 0;
+      const double j0 = xi - lq.A0, j1 = -xi - lq.A1;
+      if (j0 < 0) { qc -= lq.D0 * j0; dl += lq.D0; }   // force -D jar through the row +e_dof
+      if (j1 < 0) { qc += lq.D1 * j1; dl += lq.D1; }   // row -e_dof
       for (unsigned long long mk = ((const unsigned long long*)S(cmask))[lane]; mk; mk &= mk - 1) {
         int ci = __builtin_ctzll(mk);
         int s = slotof[ci * nv + lane];
@@ -1386,8 +1395,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
         qc += Jb[s] * cp[0] + Jb[ns + s] * cp[1] + Jb[2 * ns + s] * cp[2];
       }
       g = Ma - S(qsm)[lane] - qc;
-      S(grad)[lane] = g;
-      S(dlim)[lane] = dl;
+      if (!c.htree) S(dlim)[lane] = dl;
     }
     double gn = wave_sum(g * g);
     PROF(12);
@@ -1436,10 +1444,10 @@ __device__ __forceinline__ void newton_solve(C& c) {
     double sr;
     if (c.htree) {  // every contact touches one moving body: H keeps the tree sparsity of M (see tree_factor_solve)
       double row[8];
-      tree_rows(c, row, lane < nv ? S(dlim)[lane] : 0.0, ncon > 0);
-      sr = -tree_factor_solve(c, row, lane < nv ? S(grad)[lane] : 0.0, &hfail);
+      tree_rows(c, row, dl, ncon > 0);
+      sr = -tree_factor_solve(c, row, g, &hfail);
     } else {
-      sr = -ldl_solve_rows(c, S(H), S(H), lane < nv ? S(grad)[lane] : 0.0, &hfail);
+      sr = -ldl_solve_rows(c, S(H), S(H), g, &hfail);
     }
     if (hfail) break;
     if (lane < nv) S(search)[lane] = sr;
@@ -1448,24 +1456,25 @@ __device__ __forceinline__ void newton_solve(C& c) {
     // ---- exact line search
     double Mv = dense_Mx(c, S(search));
     contact_Jx(c, S(search));
-    // each lane keeps its rows (r = lane + 64 q) of jar, Jv, D in registers for the whole search
-    constexpr int RPL = C::NV <= 28 ? 2 : 4;  // ceil(maxefc / 64): 128 rows (Ant scenes), <= 256 otherwise
-    double rj[RPL], rjv[RPL], rD[RPL];
+    // each lane keeps its contact rows (r = lane + 64 q) and its dof's two limit rows (jar, Jv, D) in registers
+    double rj[RPL + 2], rjv[RPL + 2], rD[RPL + 2];
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       int r = lane + WAVE * q;
-      bool ok = r < nefc;
-      rjv[q] = ok ? row_Jx(c, r, S(search)) : 0.0;
-      rj[q] = ok ? S(jar)[r] : 1.0;      // inactive rows: jar > 0 and Jv = 0 never contribute
-      rD[q] = ok ? ROWD(r) : 0.0;
+      bool ok = r < nrow;
+      rjv[q] = ok ? row_Jx(c, r) : 0.0;
+      rj[q] = ok ? S(jar)[r] : 1.0;      // absent rows: jar > 0 and Jv = 0 never contribute
+      rD[q] = ok ? S(D)[r >> 2] : 0.0;
     }
+    rj[RPL] = xi - lq.A0; rjv[RPL] = sr; rD[RPL] = lq.D0;
+    rj[RPL + 1] = -xi - lq.A1; rjv[RPL + 1] = -sr; rD[RPL + 1] = lq.D1;
     double g1 = wave_sum(lane < nv ? sr * (Ma - S(qsm)[lane]) : 0.0);
     double g2 = wave_sum(lane < nv ? sr * Mv : 0.0);
     double alpha = 0, lo = 0, hi = -1, d0 = 0;
     for (int ls = 0; ls < 50; ls++) {
       double f1 = 0, f2 = 0;
 #pragma unroll
-      for (int q = 0; q < RPL; q++) {
+      for (int q = 0; q < RPL + 2; q++) {
         double j = rj[q] + alpha * rjv[q];
         if (j < 0) { f1 += rD[q] * j * rjv[q]; f2 += rD[q] * rjv[q] * rjv[q]; }
       }
@@ -1484,7 +1493,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       int r = lane + WAVE * q;
-      if (r < nefc) S(jar)[r] = rj[q] + alpha * rjv[q];
+      if (r < nrow) S(jar)[r] = rj[q] + alpha * rjv[q];
     }
     SYNC();
     double oldcost = cost;
@@ -1507,7 +1516,7 @@ __device__ __forceinline__ void forward(C& c) {
   make_constraint(c);
   // efc_vel and aref (B and K*imp*(pos-margin) were parked in Jv / jar)
   contact_Jx(c, S(qvel));
-  for (int r = lane; r < c.nefc; r += WAVE) S(aref)[r] = -S(aref)[r] * row_Jx(c, r, S(qvel)) - S(jar)[r];  // B was parked in aref
+  for (int r = lane; r < 4 * c.ncon; r += WAVE) S(aref)[r] = -S(aref)[r] * row_Jx(c, r) - S(jar)[r];  // B was parked in aref
   SYNC();
   PROF(8);
   mass_matrix(c);  // last user of the kinematic scratch; H may overwrite it from here on
@@ -1726,6 +1735,7 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
     const double* wpos = P->aux.af + P->aux.o_wpa;
     for (int i = c.lane; i < 3 * nw; i += WAVE) { smem[P->L.xipos + 3 * nb + i] = wpos[i]; smem[P->L.gaxis + 3 * nb + i] = wpos[3 * nw + i]; }
   }
+  for (int i = c.lane; i < 2 * P->mdl.nv; i += WAVE) { smem[P->L.limD + i] = 0.0; smem[P->L.limA + i] = 0.0; }   // free-joint dofs never get a limit
   __syncthreads();
   c.ncon = c.nlim = c.nefc = c.ndropped = c.use_prev = 0;
   c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = 0;
@@ -2180,7 +2190,7 @@ static void build_layout(sumo_engine* E) {
   L.maxcon = nv <= 28 ? 24 : (nv <= 36 ? 32 : 40);
   const char* mc = getenv("SUMO_MAXCON");
   if (mc && atoi(mc) > 0) L.maxcon = atoi(mc);
-  if (L.maxcon > 64) L.maxcon = 64;  // per-dof contact masks are 64 bits wide
+  { int cap = 16 * (nv <= 36 ? 2 : 3); if (L.maxcon > cap) L.maxcon = cap; }  // contact rows per lane held in registers by the line search (newton_solve RPL)
   L.maxefc = 4 * L.maxcon + 2 * nhinge;
   { const char* wm = getenv("SUMO_WARM_MODE"); L.warm_mode = wm ? atoi(wm) : 0; }
   int o = 0;
@@ -2220,7 +2230,7 @@ static void build_layout(sumo_engine* E) {
     const char* nt = getenv("SUMO_NO_TREE");
     if (nt && atoi(nt)) L.tree_ok = 0;
   }
-  L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = take(nv);
+  L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = 0;
   L.search = take(nv); L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv); L.stash = take(4);
   // contact records live from the narrow phase to the Jacobian build only: they borrow the mass matrix's storage
   if (L.msize < 14 * L.maxcon) L.msize = 14 * L.maxcon;
@@ -2237,19 +2247,16 @@ static void build_layout(sumo_engine* E) {
   }
   L.cpar = take(L.maxcon); L.cW = take(6 * L.maxcon);
   L.cp = take(3 * L.maxcon);
-  L.maxlim = 2 * nhinge;
-  L.jar = take(L.maxefc); L.D = take(L.maxlim + L.maxcon); L.aref = take(L.maxefc);
+  // row arrays hold the contact rows only (4 per contact); the limit rows live in the dof-indexed slots limD / limA
+  L.jar = take(4 * L.maxcon); L.D = take(L.maxcon); L.aref = take(4 * L.maxcon);
+  L.limD = take(2 * nv); L.limA = take(2 * nv);
   // queue of broad-phase survivors (ints, inside jar / aref); drained by the narrow phase before it can overflow
-  L.maxcand = 2 * L.maxefc >= 192 ? 192 : (2 * L.maxefc) / WAVE * WAVE;
+  L.maxcand = 8 * L.maxcon >= 192 ? 192 : (8 * L.maxcon) / WAVE * WAVE;
   L.i_base = o;
   int io = 0;
   auto itake = [&](int n) { int r = io; io += n; return r; };
   L.con_b = itake(4 * L.maxcon);
   L.stat_i = itake(E->aux.n_stat_i);
-  L.lim_dof = itake(2 * nhinge);
-  L.limrow = itake(nv);
-  if (io & 1) io++;
-  L.lim_sign = itake(2 * 2 * nhinge);  // doubles stored in the int region (2 ints each), 8-byte aligned
   L.b_slotof = io * 4;
   int bytes_slot = (L.maxcon * nv + 15) & ~15;
   L.b_dofidx = L.b_slotof + bytes_slot;
