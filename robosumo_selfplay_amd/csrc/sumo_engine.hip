@@ -174,10 +174,25 @@ __device__ __forceinline__ void fast_sincos(double x, double* sn, double* cs) {
   double r = fma(-fn, 1.57079632673412561417e+00, x);
   r = fma(-fn, 6.07710050650619224932e-11, r);
   const double z = r * r;
-  const double ps = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
-                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
-  const double pc = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  // (coefficients are rematerialised at each call: hoisted out of the step loop they would sit in registers / scratch for
+  // the whole launch)
+#define SC_K(name, val)                                                                                              \
+  double name;                                                                                                       \
+  {                                                                                                                  \
+    int lo_, hi_;                                                                                                    \
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                                                              \
+                 : "=v"(lo_), "=v"(hi_)                                                                              \
+                 : "i"((int)(__builtin_bit_cast(unsigned long long, (double)(val)) & 0xFFFFFFFFull)),                \
+                   "i"((int)(__builtin_bit_cast(unsigned long long, (double)(val)) >> 32)));                         \
+    name = __hiloint2double(hi_, lo_);                                                                               \
+  }
+  SC_K(S1, -1.66666666666666324348e-01); SC_K(S2, 8.33333333332248946124e-03); SC_K(S3, -1.98412698298579493134e-04);
+  SC_K(S4, 2.75573137070700676789e-06); SC_K(S5, -2.50507602534068634195e-08); SC_K(S6, 1.58969099521155010221e-10);
+  SC_K(C1, 4.16666666666666019037e-02); SC_K(C2, -1.38888888888741095749e-03); SC_K(C3, 2.48015872894767294178e-05);
+  SC_K(C4, -2.75573143513906633035e-07); SC_K(C5, 2.08757232129817482790e-09); SC_K(C6, -1.13596475577881948265e-11);
+#undef SC_K
+  const double ps = r + r * z * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+  const double pc = 1.0 - 0.5 * z + z * z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
   const int q = (int)fn & 3;
   const double s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
   *sn = (q & 2) ? -s0 : s0;
@@ -1407,9 +1422,14 @@ __device__ __forceinline__ void newton_solve(C& c) {
       const unsigned long long* cm = (const unsigned long long*)S(cmask);
       double hreg[C::EPL];
       unsigned long long mreg[C::EPL];
+      // (the entry words are made opaque here so that the addresses derived from them are computed in this rarely taken
+      // block instead of being hoisted to kernel entry and kept in registers / scratch for the whole launch)
+      unsigned ent[C::EPL];
+#pragma unroll
+      for (int m = 0; m < C::EPL; m++) { ent[m] = c.ent[m]; asm volatile("" : "+v"(ent[m])); }
 #pragma unroll
       for (int m = 0; m < C::EPL; m++) {
-        unsigned e = c.ent[m];
+        unsigned e = ent[m];
         int i = e == 0xFFFFu ? 0 : (int)(e >> 8), jj = e == 0xFFFFu ? 0 : (int)(e & 0xFF);
         double h = SAME_TREE(i, jj) ? S(M)[MIDX(i, jj)] : 0.0;
         if (i == jj) h += S(dlim)[i];
@@ -1418,7 +1438,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
       }
 #pragma unroll
       for (int m = 0; m < C::EPL; m++) {
-        unsigned e = c.ent[m];
+        unsigned e = ent[m];
         int i = e >> 8, jj = e & 0xFF;
         double h = hreg[m];
         for (unsigned long long mk = mreg[m]; mk; mk &= mk - 1) {
@@ -1434,7 +1454,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
       }
 #pragma unroll
       for (int m = 0; m < C::EPL; m++) {
-        unsigned e = c.ent[m];
+        unsigned e = ent[m];
         if (e != 0xFFFFu) S(H)[HP((int)(e >> 8), (int)(e & 0xFF))] = hreg[m];
       }
     }
@@ -1543,6 +1563,7 @@ __device__ __forceinline__ void forward(C& c) {
 #pragma unroll
     for (int m = 0; m < C::EPL; m++) {
       unsigned e = c.ent[m];
+      asm volatile("" : "+v"(e));   // keep the address arithmetic of this rarely taken block out of the kernel prologue
       if (e != 0xFFFFu) { int i = e >> 8, jj = e & 0xFF; S(H)[HP(i, jj)] = SAME_TREE(i, jj) ? S(M)[MIDX(i, jj)] : 0.0; }
     }
     SYNC();
