@@ -44,6 +44,14 @@ int ppo_param_count(int ob_dim, int ac_dim);
 int ppo_forward(const float* params, const float* obs, int n, int obs_stride, int ob_dim, int ac_dim, int flags,
                 const float* noise, const float* given_action, float* action_out, float* neglogp_out,
                 float* value_out, float* mean_out, void* stream);
+/* Same, for the fixed opponents of the policy zoo (robosumo/robosumo/policy_zoo/policy.py:23-91, utils.py:9-33): tanh
+ * hidden units (flag PPO_FWD_TANH) and the running-mean observation filter clip((obs - mean) * invstd, -clip, clip)
+ * applied to the ob_dim columns read (obs_mean / obs_invstd float32 [ob_dim]; both NULL = no filter). */
+#define PPO_FWD_TANH 4
+int ppo_forward_filtered(const float* params, const float* obs, int n, int obs_stride, int ob_dim, int ac_dim, int flags,
+                         const float* obs_mean, const float* obs_invstd, float obs_clip, const float* noise,
+                         const float* given_action, float* action_out, float* neglogp_out, float* value_out,
+                         float* mean_out, void* stream);
 
 /* info float64 [n][2][8] as written by sumo_step (slot 6 shaping, slot 3 main); reward_out float32 [2][n]
  * (agent-major, one time slice of the rollout buffer) = alpha*shaping + (1-alpha)*main evaluated in float64. */

@@ -285,3 +285,31 @@ def adam_step(params, grads, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-5):
         out_m.append(mm)
         out_v.append(vv)
     return out_p, out_m, out_v
+
+
+# ---------------------------------------------------------------------------------------------------------
+# policy-zoo MLP nets (robosumo/robosumo/policy_zoo/policy.py:23-79, utils.py:9-33).  `p` maps the TF variable names
+# ("obsfilter/sum", "polfc1/w", ...) to float32 arrays, as robosumo_selfplay_amd.policy_zoo.split_zoo_mlp returns.
+# No recorded outputs of these nets exist in the reference tree: parity unpinned (the flat layout IS pinned by the
+# shipped files, tests/golden/zoo_mlp_layout.json).
+# ---------------------------------------------------------------------------------------------------------
+def zoo_filter(p, prefix):
+    cnt = np.float32(p[prefix + "/count"])
+    mean = (p[prefix + "/sum"] / cnt).astype(np.float32)
+    var = (p[prefix + "/sumsq"] / cnt).astype(np.float32) - np.square(mean)
+    return mean, np.sqrt(np.maximum(var, np.float32(1e-2))).astype(np.float32)
+
+
+def zoo_mlp_forward(p, obs):
+    """obs float32 [n, ob_dim] -> (mean [n, A], vpred [n], logstd [A])."""
+    obs = np.asarray(obs, np.float32)
+    om, osd = zoo_filter(p, "obsfilter")
+    rm, rs = zoo_filter(p, "retfilter")
+    obz = np.clip((obs - om) / osd, -5.0, 5.0).astype(np.float32)
+    h = np.tanh(obz @ p["vffc1/w"] + p["vffc1/b"])
+    h = np.tanh(h @ p["vffc2/w"] + p["vffc2/b"])
+    vpred = (h @ p["vffinal/w"] + p["vffinal/b"])[:, 0] * rs + rm
+    h = np.tanh(obz @ p["polfc1/w"] + p["polfc1/b"])
+    h = np.tanh(h @ p["polfc2/w"] + p["polfc2/b"])
+    mean = h @ p["polfinal/w"] + p["polfinal/b"]
+    return mean.astype(np.float32), vpred.astype(np.float32), p["logstd"].ravel().astype(np.float32)

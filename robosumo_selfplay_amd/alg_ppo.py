@@ -41,7 +41,7 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
           ent_coef=0.0, lr=3e-4, vf_coef=0.5, max_grad_norm=0.5, gamma=0.99, lam=0.95, rho_bar=1.0, c_bar=1.0, log_interval=10,
           nminibatches=4, noptepochs=4, cliprange=0.2, save_interval=1, load_path=None, model_fn=None, update_fn=None, init_fn=None,
           nagent=1, anneal_bound=500, vgap=None, kl_threshold=None, neglogp_threshold=10000.0, log_dir=None, comm=None,
-          verbose=True, **network_kwargs):
+          verbose=True, fix_opponent_path=None, **network_kwargs):
     import torch
     if seed is not None:                                                # set_global_seeds (misc_util.py:48-62)
         np.random.seed(seed)
@@ -94,7 +94,16 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         frac = 1.0 - (update - 1.0) / nupdates
         lrnow, cliprangenow = lr(frac), cliprange(frac)
         # ---- opponent selection (alg_ppo.py:191-247); rank 0 decides, everyone loads the same file
-        if update == 1:
+        if opponent_mode == "fix":                                       # alg_ppo.py:194-206: a policy-zoo MLP net
+            if update == 1:
+                from .policy_zoo import FixedOpponentModel, load_zoo_policy
+                if fix_opponent_path is None:
+                    raise ValueError("opponent_mode='fix' needs fix_opponent_path=<policy_zoo .npy> (reference default: "
+                                     "robosumo/robosumo/policy_zoo/assets/ant/mlp/agent-params-v3.npy)")
+                zoo = load_zoo_policy(fix_opponent_path, ac_space.shape[0], device=dev)
+                zoo.seed((seed or 0) * 1000 + 17 + rank)
+                runner.models[1] = FixedOpponentModel(zoo)
+        elif update == 1:
             runner.models[1].load(osp.join(checkdir, "00000"))
             history["version_gap"].append(0)
         else:
@@ -116,7 +125,7 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
                 rd = rd / rd.sum() if rd.sum() > 0 else np.full(len(rd), 1.0 / len(rd))
                 idx_choice = int(sub[np.random.choice(len(rd), 1, p=rd)[0]])
             else:
-                raise ValueError("opponent_mode %r (the 'fix' mode needs the TF policy zoo: SURVEY.md §8(f) rank 2)" % opponent_mode)
+                raise ValueError("opponent_mode %r" % (opponent_mode,))
             if comm is not None:
                 c = torch.tensor([idx_choice], device=dev)
                 torch.distributed.broadcast(c, 0, group=comm)

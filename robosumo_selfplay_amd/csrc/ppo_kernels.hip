@@ -62,8 +62,10 @@ struct Net { const float *w0, *b0, *w1, *b1, *w2, *b2; int nout; };
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 // stage 16 rows of obs (row ids from idx, or consecutive) into xbuf[16][XS], zero padded
+// (optional observation filter of the policy-zoo nets: clip((x - mean) * invstd, -clip, clip))
 __device__ __forceinline__ void stage_x(float* xbuf, int XS, const float* obs, int obs_stride, int D, const int32_t* idx, int r0,
-                                        int n, int lane) {
+                                        int n, int lane, const float* f_mean = nullptr, const float* f_invstd = nullptr,
+                                        float f_clip = 0.0f) {
   for (int e = lane; e < 16 * XS; e += WAVE) {
     int r = e / XS, c = e - r * XS;
     float v = 0.0f;
@@ -71,6 +73,7 @@ __device__ __forceinline__ void stage_x(float* xbuf, int XS, const float* obs, i
     if (row < n && c < D) {
       int src = idx ? idx[row] : row;
       v = obs[(size_t)src * obs_stride + c];
+      if (f_mean) v = fminf(fmaxf((v - f_mean[c]) * f_invstd[c], -f_clip), f_clip);
     }
     xbuf[e] = v;
   }
@@ -78,6 +81,7 @@ __device__ __forceinline__ void stage_x(float* xbuf, int XS, const float* obs, i
 
 // forward of one trunk on the staged tile.  h1buf/h2buf [16][HS] receive the relu activations; returns the head tile
 // (D layout: lane (i = lane&15, kq = lane>>4) holds rows 4kq+r, column i; columns >= nout are zero + garbage-free).
+template <bool TANH = false>
 __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf, int XS, int D, float* h1buf, float* h2buf, int lane) {
   const int i = lane & 15, kq = lane >> 4;
   const int Dp = (D + 3) & ~3;
@@ -98,7 +102,7 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
   for (int ct = 0; ct < 4; ct++) {
     float bias = net.b0[ct * 16 + i];
 #pragma unroll
-    for (int r = 0; r < 4; r++) h1buf[(4 * kq + r) * HS + ct * 16 + i] = fmaxf(acc[ct][r] + bias, 0.0f);
+    for (int r = 0; r < 4; r++) { float z = acc[ct][r] + bias; h1buf[(4 * kq + r) * HS + ct * 16 + i] = TANH ? tanhf(z) : fmaxf(z, 0.0f); }
     acc[ct] = (f32x4){0, 0, 0, 0};
   }
   wave_sync();
@@ -112,7 +116,7 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
   for (int ct = 0; ct < 4; ct++) {
     float bias = net.b1[ct * 16 + i];
 #pragma unroll
-    for (int r = 0; r < 4; r++) h2buf[(4 * kq + r) * HS + ct * 16 + i] = fmaxf(acc[ct][r] + bias, 0.0f);
+    for (int r = 0; r < 4; r++) { float z = acc[ct][r] + bias; h2buf[(4 * kq + r) * HS + ct * 16 + i] = TANH ? tanhf(z) : fmaxf(z, 0.0f); }
   }
   wave_sync();
   f32x4 out = (f32x4){0, 0, 0, 0};
@@ -153,6 +157,8 @@ __device__ __forceinline__ Net vf_net(const float* p, const ParamLayout& L) {
 struct FwdArgs {
   const float *params, *obs, *noise, *given;
   float *action, *neglogp, *value, *mean;
+  const float *f_mean, *f_invstd;   // optional observation filter (policy-zoo nets)
+  float f_clip;
   int n, obs_stride, flags, XS;
   ParamLayout L;
 };
@@ -167,11 +173,12 @@ __global__ void __launch_bounds__(256) ppo_forward_kernel(FwdArgs a) {
   float* base = smem_f + wid * (16 * XS + 2 * 16 * HS);
   float *xbuf = base, *h1 = base + 16 * XS, *h2 = h1 + 16 * HS;
   const int i = lane & 15, kq = lane >> 4;
-  stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, lane);
+  stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, lane, a.f_mean, a.f_invstd, a.f_clip);
   wave_sync();
+  const bool use_tanh = (a.flags & PPO_FWD_TANH) != 0;
   if (a.flags & PPO_FWD_PI) {
     Net net = pi_net(a.params, a.L);
-    f32x4 mean = trunk_forward(net, xbuf, XS, D, h1, h2, lane);
+    f32x4 mean = use_tanh ? trunk_forward<true>(net, xbuf, XS, D, h1, h2, lane) : trunk_forward<false>(net, xbuf, XS, D, h1, h2, lane);
     const bool col = i < A;
     float logstd = col ? a.params[a.L.logstd + i] : 0.0f;
     float std = expf(logstd);
@@ -195,7 +202,7 @@ __global__ void __launch_bounds__(256) ppo_forward_kernel(FwdArgs a) {
   }
   if (a.flags & PPO_FWD_VF) {
     Net net = vf_net(a.params, a.L);
-    f32x4 v = trunk_forward(net, xbuf, XS, D, h1, h2, lane);
+    f32x4 v = use_tanh ? trunk_forward<true>(net, xbuf, XS, D, h1, h2, lane) : trunk_forward<false>(net, xbuf, XS, D, h1, h2, lane);
     if (a.value && i == 0) {
 #pragma unroll
       for (int r = 0; r < 4; r++) { int row = r0 + 4 * kq + r; if (row < a.n) a.value[row] = v[r]; }
@@ -203,15 +210,28 @@ __global__ void __launch_bounds__(256) ppo_forward_kernel(FwdArgs a) {
   }
 }
 
+extern "C" int ppo_forward_filtered(const float* params, const float* obs, int n, int obs_stride, int ob_dim, int ac_dim, int flags,
+                                    const float* obs_mean, const float* obs_invstd, float obs_clip, const float* noise,
+                                    const float* given_action, float* action_out, float* neglogp_out, float* value_out,
+                                    float* mean_out, void* stream);
 extern "C" int ppo_forward(const float* params, const float* obs, int n, int obs_stride, int ob_dim, int ac_dim, int flags,
                            const float* noise, const float* given_action, float* action_out, float* neglogp_out,
                            float* value_out, float* mean_out, void* stream) {
+  return ppo_forward_filtered(params, obs, n, obs_stride, ob_dim, ac_dim, flags, nullptr, nullptr, 0.0f, noise, given_action,
+                              action_out, neglogp_out, value_out, mean_out, stream);
+}
+extern "C" int ppo_forward_filtered(const float* params, const float* obs, int n, int obs_stride, int ob_dim, int ac_dim, int flags,
+                                    const float* obs_mean, const float* obs_invstd, float obs_clip, const float* noise,
+                                    const float* given_action, float* action_out, float* neglogp_out, float* value_out,
+                                    float* mean_out, void* stream) {
   if (!params || !obs || n <= 0) FAIL(-1, "bad arguments");
   if (ac_dim < 1 || ac_dim > MAXA) FAIL(-2, "ac_dim %d not in [1,%d]", ac_dim, MAXA);
   if (ob_dim < 1 || ob_dim > 512 || obs_stride < ob_dim) FAIL(-3, "bad ob_dim/obs_stride");
+  if ((obs_mean == nullptr) != (obs_invstd == nullptr)) FAIL(-4, "obs_mean and obs_invstd must be given together");
   FwdArgs a;
   a.params = params; a.obs = obs; a.noise = noise; a.given = given_action; a.action = action_out; a.neglogp = neglogp_out;
   a.value = value_out; a.mean = mean_out; a.n = n; a.obs_stride = obs_stride; a.flags = flags; a.XS = x_stride(ob_dim);
+  a.f_mean = obs_mean; a.f_invstd = obs_invstd; a.f_clip = obs_clip;
   a.L = make_layout(ob_dim, ac_dim);
   size_t lds = (size_t)4 * (16 * a.XS + 2 * 16 * HS) * sizeof(float);
   int tiles = (n + 15) / 16;

@@ -5,10 +5,10 @@ import os
 from . import build as _build
 
 NSTATS = 8
-FWD_PI, FWD_VF = 1, 2
+FWD_PI, FWD_VF, FWD_TANH = 1, 2, 4
 _LIB = None
 
-EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
+EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_forward_filtered", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
            "ppo_adv_normalize", "ppo_grad_workspace_bytes", "ppo_grad", "ppo_clip_adam")
 
 
@@ -27,6 +27,7 @@ def lib():
         L.ppo_last_error.restype = C.c_char_p
         L.ppo_param_count.argtypes = [i32, i32]
         L.ppo_forward.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.ppo_forward_filtered.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
         L.ppo_reward_mix.argtypes = [vp, i32, f64, vp, i32, vp]
         L.ppo_vtrace.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp, vp]
         L.ppo_adv_moments.argtypes = [vp, vp, vp, i32, vp, vp]
