@@ -177,8 +177,8 @@ def main():
         B = algorithmic_bytes_per_env_step(model)
         traffic = None
         try:   # PMC traffic is collected offline with rocprofv3 (profiles/README.md); reported only for the profiled config
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pj["env_id"] == args.env_id and pj["envs"] == N:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")))   # newest collection
+            if ("<%d>" % model.nv) in pj["kernel"] and pj["envs"] == N:
                 traffic = pj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
