@@ -53,6 +53,32 @@ int ppo_forward_filtered(const float* params, const float* obs, int n, int obs_s
                          const float* given_action, float* action_out, float* neglogp_out, float* value_out,
                          float* mean_out, void* stream);
 
+/* One time step of an LSTM policy for n rows (envs), state carried by the caller.  Covers the two recurrent nets of the
+ * reference tree:
+ *   - baselines `lstm(nlstm)` (baselines/baselines/common/models.py:131-183 + a2c/utils.py:82-103): x = obs, gates
+ *     z = x*wx + h*wh + b split as (i, f, o, u), c,h first multiplied by (1 - mask), shared latent for both heads
+ *     (policies.py:160-181);  gate_order = PPO_LSTM_GATES_IFOU, forget_bias = 0
+ *   - policy-zoo `LSTMPolicy` (robosumo/robosumo/policy_zoo/policy.py:94-199): observation filter, one relu embedding
+ *     layer, tf BasicLSTMCell (kernel [x|h] -> (i, j, f, o), forget bias 1);  gate_order = PPO_LSTM_GATES_IJFO
+ * All weights are [in][out] row-major float32 device pointers.  emb_w == NULL: no embedding (x = filtered obs).
+ * wh points at the recurrent rows (for a TF kernel: kernel + x_dim * 4 * hidden).  c / h are read and overwritten
+ * ([n] rows of `state_stride` floats each); mask float32 [n] or NULL.  Heads (each optional): head_w [hidden][ac_dim],
+ * head_b, logstd -> mean / action / neglogp exactly as ppo_forward; vf_w [hidden], vf_b -> value_out. */
+#define PPO_LSTM_GATES_IFOU 0
+#define PPO_LSTM_GATES_IJFO 1
+typedef struct ppo_lstm_net {
+  int ob_dim, emb_dim, hidden, ac_dim, gate_order;
+  float forget_bias;
+  const float *obs_mean, *obs_invstd; float obs_clip;     /* optional observation filter (both NULL = none) */
+  const float *emb_w, *emb_b;                             /* optional embedding [ob_dim][emb_dim] + relu */
+  const float *wx, *wh, *b;                               /* [x_dim][4*hidden], [hidden][4*hidden], [4*hidden] */
+  const float *head_w, *head_b, *logstd;                  /* optional Gaussian head */
+  const float *vf_w, *vf_b;                               /* optional value head */
+} ppo_lstm_net;
+int ppo_lstm_step(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
+                  int state_stride, const float* noise, const float* given_action, float* action_out, float* neglogp_out,
+                  float* value_out, float* mean_out, void* stream);
+
 /* info float64 [n][2][8] as written by sumo_step (slot 6 shaping, slot 3 main); reward_out float32 [2][n]
  * (agent-major, one time slice of the rollout buffer) = alpha*shaping + (1-alpha)*main evaluated in float64. */
 int ppo_reward_mix(const double* info, int n, double alpha, float* reward_out, int agent_stride, void* stream);

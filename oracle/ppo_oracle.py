@@ -313,3 +313,50 @@ def zoo_mlp_forward(p, obs):
     h = np.tanh(h @ p["polfc2/w"] + p["polfc2/b"])
     mean = h @ p["polfinal/w"] + p["polfinal/b"]
     return mean.astype(np.float32), vpred.astype(np.float32), p["logstd"].ravel().astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# recurrent nets
+# ---------------------------------------------------------------------------------------------------------
+def _sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+
+
+def lstm_step_baselines(wx, wh, b, x, state, mask):
+    """a2c/utils.py:90-103, one step: state [n, 2*nh] = (c | h); mask [n] zeroes the state first."""
+    nh = wh.shape[0]
+    c, h = state[:, :nh].copy(), state[:, nh:].copy()
+    if mask is not None:
+        m = np.asarray(mask, np.float32)[:, None]
+        c, h = c * (1 - m), h * (1 - m)
+    z = x.astype(np.float32) @ wx + h @ wh + b
+    i, f, o, u = z[:, :nh], z[:, nh:2 * nh], z[:, 2 * nh:3 * nh], z[:, 3 * nh:]
+    c = _sigmoid(f) * c + _sigmoid(i) * np.tanh(u)
+    h = _sigmoid(o) * np.tanh(c)
+    return h.astype(np.float32), np.concatenate([c, h], axis=1).astype(np.float32)
+
+
+def basic_lstm_cell(kernel, bias, x, c, h, forget_bias=1.0):
+    """tf.contrib.rnn.BasicLSTMCell: concat([x, h]) @ kernel + bias -> (i, j, f, o); c' = c*sig(f + fb) + sig(i)*tanh(j)."""
+    z = np.concatenate([x, h], axis=1).astype(np.float32) @ kernel + bias
+    nh = h.shape[1]
+    i, j, f, o = z[:, :nh], z[:, nh:2 * nh], z[:, 2 * nh:3 * nh], z[:, 3 * nh:]
+    c2 = c * _sigmoid(f + np.float32(forget_bias)) + _sigmoid(i) * np.tanh(j)
+    h2 = np.tanh(c2) * _sigmoid(o)
+    return c2.astype(np.float32), h2.astype(np.float32)
+
+
+def zoo_lstm_step(p, obs, state):
+    """policy_zoo/policy.py:94-199, one step.  state [4][n][H] = value c, value h, policy c, policy h.
+    Returns (mean [n, A], vpred [n], new state)."""
+    obs = np.asarray(obs, np.float32)
+    om, osd = zoo_filter(p, "obsfilter")
+    rm, rs = zoo_filter(p, "retfilter")
+    obz = np.clip((obs - om) / osd, -5.0, 5.0).astype(np.float32)
+    ev = np.maximum(obz @ p["v/emb/w"] + p["v/emb/b"], 0.0)
+    vc, vh = basic_lstm_cell(p["lstmv/kernel"], p["lstmv/bias"], ev, state[0], state[1])
+    vpred = (vh @ p["v/out/w"] + p["v/out/b"])[:, 0] * rs + rm
+    ep = np.maximum(obz @ p["p/emb/w"] + p["p/emb/b"], 0.0)
+    pc, ph = basic_lstm_cell(p["lstmp/kernel"], p["lstmp/bias"], ep, state[2], state[3])
+    mean = ph @ p["p/out/w"] + p["p/out/b"]
+    return mean.astype(np.float32), vpred.astype(np.float32), np.stack([vc, vh, pc, ph])

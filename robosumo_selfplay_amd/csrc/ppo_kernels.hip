@@ -246,6 +246,168 @@ extern "C" int ppo_forward_filtered(const float* params, const float* obs, int n
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// recurrent policies: one LSTM time step (see sumo_ppo.h).  One wave per 16-row tile, one wave per workgroup.
+// LDS per wave: x [16][XS] | emb [16][HS] | h_prev [16][HP] | h_new [16][HP]
+// ---------------------------------------------------------------------------------------------------------
+#define LSTM_MAXH 128
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct LstmArgs {
+  ppo_lstm_net net;
+  const float *obs, *mask, *noise, *given;
+  float *c, *h, *action, *neglogp, *value, *mean;
+  int n, obs_stride, state_stride, XS, HP;
+};
+
+template <int NH, int ORDER>   // hidden units: 64 or 128; gate order (static so the gate tiles are static registers)
+__global__ void __launch_bounds__(64) ppo_lstm_step_kernel(LstmArgs a) {
+  const int lane = threadIdx.x, r0 = blockIdx.x * 16;
+  const ppo_lstm_net& N = a.net;
+  const int D = N.ob_dim, E = N.emb_dim, A = N.ac_dim, XS = a.XS, HP = a.HP;
+  float* xbuf = smem_f;
+  float* ebuf = xbuf + 16 * XS;
+  float* hprev = ebuf + 16 * HS;
+  float* hnew = hprev + 16 * HP;
+  const int i = lane & 15, kq = lane >> 4;
+  stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, lane, N.obs_mean, N.obs_invstd, N.obs_clip);
+  for (int e = lane; e < 16 * NH; e += WAVE) {   // h_prev * (1 - mask)
+    int r = e / NH, k = e - r * NH, row = r0 + r;
+    float v = 0.0f;
+    if (row < a.n) { v = a.h[(size_t)row * a.state_stride + k]; if (a.mask) v *= 1.0f - a.mask[row]; }
+    hprev[r * HP + k] = v;
+  }
+  wave_sync();
+  // ---- optional embedding: relu(x * We + be), 64 wide
+  const float* xin = xbuf; int xk = D, xs = XS;
+  if (N.emb_w) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
+    const int Dp = (D + 3) & ~3;
+    for (int k0 = 0; k0 < Dp; k0 += 4) {
+      int k = k0 + kq;
+      float av = xbuf[i * XS + k];
+      bool ok = k < D;
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) { float b = (ok && ct * 16 + i < E) ? N.emb_w[k * E + ct * 16 + i] : 0.0f; acc[ct] = MFMA(av, b, acc[ct]); }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) {
+      float bias = ct * 16 + i < E ? N.emb_b[ct * 16 + i] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) ebuf[(4 * kq + r) * HS + ct * 16 + i] = fmaxf(acc[ct][r] + bias, 0.0f);
+    }
+    wave_sync();
+    xin = ebuf; xk = E; xs = HS;
+  }
+  // ---- gates z = x * wx + h_prev * wh + b : 4*NH columns = NH/4 tiles of 16
+  constexpr int NT = NH / 4;
+  f32x4 z[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) z[ct] = (f32x4){0, 0, 0, 0};
+  {
+    const int xp = (xk + 3) & ~3;
+    for (int k0 = 0; k0 < xp; k0 += 4) {
+      int k = k0 + kq;
+      float av = xin[i * xs + k];
+      bool ok = k < xk;
+      const float* wrow = N.wx + (size_t)(ok ? k : 0) * 4 * NH;
+#pragma unroll
+      for (int ct = 0; ct < NT; ct++) z[ct] = MFMA(av, ok ? wrow[ct * 16 + i] : 0.0f, z[ct]);
+    }
+    for (int k0 = 0; k0 < NH; k0 += 4) {
+      int k = k0 + kq;
+      float av = hprev[i * HP + k];
+      const float* wrow = N.wh + (size_t)k * 4 * NH;
+#pragma unroll
+      for (int ct = 0; ct < NT; ct++) z[ct] = MFMA(av, wrow[ct * 16 + i], z[ct]);
+    }
+  }
+  // ---- cell update.  Lane (i, kq) holds rows 4kq+r of columns ct*16+i: all four gates of unit j = ut*16+i
+  constexpr int gi = 0, gf = ORDER == PPO_LSTM_GATES_IFOU ? 1 : 2, go = ORDER == PPO_LSTM_GATES_IFOU ? 2 : 3,
+                gu = ORDER == PPO_LSTM_GATES_IFOU ? 3 : 1;
+  constexpr int UT = NH / 16;   // unit tiles
+#pragma unroll
+  for (int ut = 0; ut < UT; ut++) {
+    const int j = ut * 16 + i;
+    const f32x4 zi = z[gi * UT + ut], zf = z[gf * UT + ut], zo = z[go * UT + ut], zu = z[gu * UT + ut];
+    const float bi = N.b[gi * NH + j], bf = N.b[gf * NH + j] + N.forget_bias, bo = N.b[go * NH + j], bu = N.b[gu * NH + j];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 4 * kq + r;
+      float cp = 0.0f;
+      if (row < a.n) { cp = a.c[(size_t)row * a.state_stride + j]; if (a.mask) cp *= 1.0f - a.mask[row]; }
+      const float ig = sigmoidf_(zi[r] + bi), fg = sigmoidf_(zf[r] + bf), og = sigmoidf_(zo[r] + bo), ug = tanhf(zu[r] + bu);
+      const float cn = fg * cp + ig * ug, hn = og * tanhf(cn);
+      if (row < a.n) { a.c[(size_t)row * a.state_stride + j] = cn; a.h[(size_t)row * a.state_stride + j] = hn; }
+      hnew[(4 * kq + r) * HP + j] = hn;
+    }
+  }
+  wave_sync();
+  // ---- heads on the new latent
+  if (N.head_w) {
+    f32x4 m4 = (f32x4){0, 0, 0, 0};
+    const bool col = i < A;
+    for (int k0 = 0; k0 < NH; k0 += 4) { int k = k0 + kq; m4 = MFMA(hnew[i * HP + k], col ? N.head_w[k * A + i] : 0.0f, m4); }
+    const float hb = col ? N.head_b[i] : 0.0f, logstd = col ? N.logstd[i] : 0.0f, std = expf(logstd);
+    const float sum_logstd = row16_sum(logstd);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 4 * kq + r;
+      const bool ok = col && row < a.n;
+      const float m = m4[r] + hb;
+      float act = m;
+      if (ok) {
+        if (a.given) act = a.given[(size_t)row * A + i];
+        else if (a.noise) act = m + std * a.noise[(size_t)row * A + i];
+        if (a.action) a.action[(size_t)row * A + i] = act;
+        if (a.mean) a.mean[(size_t)row * A + i] = m;
+      }
+      const float zz = ok ? (act - m) / std : 0.0f;
+      const float ss = row16_sum(zz * zz);
+      if (a.neglogp && i == 0 && row < a.n) a.neglogp[row] = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
+    }
+  }
+  if (N.vf_w && a.value) {
+    f32x4 v4 = (f32x4){0, 0, 0, 0};
+    for (int k0 = 0; k0 < NH; k0 += 4) { int k = k0 + kq; v4 = MFMA(hnew[i * HP + k], i == 0 ? N.vf_w[k] : 0.0f, v4); }
+    if (i == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { int row = r0 + 4 * kq + r; if (row < a.n) a.value[row] = v4[r] + N.vf_b[0]; }
+    }
+  }
+}
+
+extern "C" int ppo_lstm_step(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
+                             int state_stride, const float* noise, const float* given_action, float* action_out,
+                             float* neglogp_out, float* value_out, float* mean_out, void* stream) {
+  if (!net || !obs || !c || !h || n <= 0) FAIL(-1, "bad arguments");
+  if (net->hidden != 64 && net->hidden != 128) FAIL(-2, "hidden %d: only 64 and 128 are built", net->hidden);
+  if (net->ob_dim < 1 || net->ob_dim > 512 || obs_stride < net->ob_dim) FAIL(-3, "bad ob_dim/obs_stride");
+  if (net->emb_w && (net->emb_dim < 1 || net->emb_dim > 64 || !net->emb_b)) FAIL(-4, "embedding width %d not in [1,64]", net->emb_dim);
+  if (!net->wx || !net->wh || !net->b) FAIL(-5, "missing LSTM weights");
+  if (net->head_w && (net->ac_dim < 1 || net->ac_dim > MAXA || !net->head_b || !net->logstd)) FAIL(-6, "bad Gaussian head");
+  if ((net->obs_mean == nullptr) != (net->obs_invstd == nullptr)) FAIL(-7, "obs_mean and obs_invstd must be given together");
+  if (state_stride < net->hidden) FAIL(-8, "state_stride < hidden");
+  LstmArgs a;
+  a.net = *net; a.obs = obs; a.mask = mask; a.noise = noise; a.given = given_action; a.c = c; a.h = h; a.action = action_out;
+  a.neglogp = neglogp_out; a.value = value_out; a.mean = mean_out; a.n = n; a.obs_stride = obs_stride; a.state_stride = state_stride;
+  a.XS = x_stride(net->ob_dim); a.HP = net->hidden + 2;
+  size_t lds = (size_t)(16 * a.XS + 16 * HS + 2 * 16 * a.HP) * sizeof(float);
+  int tiles = (n + 15) / 16;
+  if (net->gate_order != PPO_LSTM_GATES_IFOU && net->gate_order != PPO_LSTM_GATES_IJFO) FAIL(-9, "unknown gate order %d", net->gate_order);
+  const bool ifou = net->gate_order == PPO_LSTM_GATES_IFOU;
+  dim3 g(tiles), b(64);
+  hipStream_t st = (hipStream_t)stream;
+  if (net->hidden == 64 && ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IFOU>), g, b, lds, st, a);
+  else if (net->hidden == 64) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IJFO>), g, b, lds, st, a);
+  else if (ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IFOU>), g, b, lds, st, a);
+  else hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IJFO>), g, b, lds, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // rollout arithmetic
 // ---------------------------------------------------------------------------------------------------------
 __global__ void ppo_reward_mix_kernel(const double* info, int n, double alpha, float* out, int agent_stride) {

@@ -156,3 +156,82 @@ class PolicyWithValue(object):
         r = self.evaluate(observation, ppo_capi.FWD_PI | ppo_capi.FWD_VF, given_action=given_action)
         np_in = isinstance(observation, np.ndarray)
         return self._ret(r["value"], np_in), self._ret(r["neglogp"], np_in)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# recurrent policy: baselines ``lstm(nlstm=128)`` (baselines/baselines/common/models.py:131-183, a2c/utils.py:82-103) with
+# the shared latent feeding both heads (policies.py:160-181 of the reference: ``value_network='copy'`` is not available
+# for recurrent nets).  ACTING ONLY so far: the reference's recurrent training branch is dead code (it passes the states
+# as IS_weight, alg_ppo.py:408-421), and the BPTT kernel is not built yet -- PPOModel refuses to train this policy.
+# ---------------------------------------------------------------------------------------------------------------------
+LSTM_PARAM_NAMES = ["pi/lstm/wx", "pi/lstm/wh", "pi/lstm/b", "pi/w", "pi/b", "pi/logstd", "vf/w", "vf/b"]
+
+
+def lstm_param_shapes(ob_dim, ac_dim, nlstm=128):
+    return [(ob_dim, 4 * nlstm), (nlstm, 4 * nlstm), (4 * nlstm,), (nlstm, ac_dim), (ac_dim,), (1, ac_dim), (nlstm, 1), (1,)]
+
+
+def init_lstm_param_list(ob_dim, ac_dim, nlstm=128, rng=None):
+    """a2c/utils.py:85-88 (ortho_init(1.0) for wx / wh, zero bias) + the heads of policies.py:50,70."""
+    rng = rng or np.random
+    return [ortho_init((ob_dim, 4 * nlstm), 1.0, rng), ortho_init((nlstm, 4 * nlstm), 1.0, rng), np.zeros(4 * nlstm, np.float32),
+            ortho_init((nlstm, ac_dim), 0.01, rng), np.zeros(ac_dim, np.float32), np.zeros((1, ac_dim), np.float32),
+            ortho_init((nlstm, 1), 1.0, rng), np.zeros(1, np.float32)]
+
+
+class LstmPolicyWithValue(object):
+    """Device evaluation of one baselines-LSTM parameter list.  ``step(obs, S=state, M=done)`` / ``value`` follow
+    policies.py:84-128 with the extra feeds of models.py:163-170: state [n, 2*nlstm] = (c | h), M = done flags of the
+    previous step (state rows are zeroed where M is set before the cell runs)."""
+
+    def __init__(self, ob_dim, ac_dim, param_list, nlstm=128, device=0):
+        import ctypes as C
+        import torch
+        self._t, self._C = torch, C
+        self.device = torch.device("cuda", int(device))
+        self.ob_dim, self.ac_dim, self.nlstm = int(ob_dim), int(ac_dim), int(nlstm)
+        shapes = lstm_param_shapes(ob_dim, ac_dim, nlstm)
+        assert len(param_list) == len(shapes) and all(tuple(np.shape(p)) == s for p, s in zip(param_list, shapes))
+        self.tensors = [torch.from_numpy(np.ascontiguousarray(p, np.float32)).to(self.device) for p in param_list]
+        wx, wh, b, pw, pb, logstd, vw, vb = self.tensors
+        n = ppo_capi.LstmNet()
+        n.ob_dim, n.emb_dim, n.hidden, n.ac_dim = self.ob_dim, 0, self.nlstm, self.ac_dim
+        n.gate_order, n.forget_bias = ppo_capi.LSTM_GATES_IFOU, 0.0
+        n.wx, n.wh, n.b = wx.data_ptr(), wh.data_ptr(), b.data_ptr()
+        n.head_w, n.head_b, n.logstd, n.vf_w, n.vf_b = pw.data_ptr(), pb.data_ptr(), logstd.data_ptr(), vw.data_ptr(), vb.data_ptr()
+        self._net = n
+        self.gen = torch.Generator(device=self.device)
+
+    def initial_state(self, nenv):
+        return np.zeros((nenv, 2 * self.nlstm), np.float32)                      # models.py:176
+
+    def seed(self, s):
+        self.gen.manual_seed(int(s))
+
+    def _run(self, obs, S, M, given_action=None, deterministic=False, keep_state=True):
+        t = self._t
+        np_in = isinstance(obs, np.ndarray)
+        dev = lambda a, dt=np.float32: t.from_numpy(np.ascontiguousarray(a, dt)).to(self.device) if not t.is_tensor(a) else a
+        x, st = dev(obs).reshape(-1, self.ob_dim), dev(S).clone() if not keep_state or not t.is_tensor(S) else S
+        n, A, H = x.shape[0], self.ac_dim, self.nlstm
+        mask = None if M is None else dev(np.asarray(M, np.float32) if not t.is_tensor(M) else M.to(t.float32))
+        action = t.empty((n, A), dtype=t.float32, device=self.device)
+        neglogp = t.empty(n, dtype=t.float32, device=self.device)
+        value = t.empty(n, dtype=t.float32, device=self.device)
+        given = None if given_action is None else dev(given_action).reshape(n, A).contiguous()
+        noise = None if (deterministic or given is not None) else t.randn((n, A), generator=self.gen, device=self.device, dtype=t.float32)
+        ppo_capi.chk(ppo_capi.lib().ppo_lstm_step(self._C.byref(self._net), x.data_ptr(), n, x.stride(0) if n > 1 else x.shape[1],
+                                                  ppo_capi.ptr(mask), st.data_ptr(), st.data_ptr() + 4 * H, 2 * H, ppo_capi.ptr(noise),
+                                                  ppo_capi.ptr(given), action.data_ptr(), neglogp.data_ptr(), value.data_ptr(), None,
+                                                  t.cuda.current_stream(self.device).cuda_stream))
+        out = lambda z: z.cpu().numpy() if np_in else z
+        return out(action), out(value), out(st), out(neglogp)
+
+    def step(self, observation, S=None, M=None, deterministic=False, **extra_feed):
+        return self._run(observation, S, M, deterministic=deterministic)
+
+    def value(self, ob, S=None, M=None, **kwargs):
+        return self._run(ob, S, M, deterministic=True, keep_state=False)[1]
+
+    def action_probability(self, observation, given_action=None, S=None, M=None, **extra_feed):
+        return self._run(observation, S, M, given_action=given_action, keep_state=False)[3]

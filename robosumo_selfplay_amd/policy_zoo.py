@@ -9,7 +9,7 @@ Reference:
     deterministic on obs[:,1,:-1], 'winner' bookkeeping)
   * alg_ppo.py:194-206                             ``opponent_mode='fix'``
 
-Only the MLP zoo nets are built (the LSTM ones need a recurrent kernel: SURVEY.md §8(f) rank 2, next round).
+MLP and LSTM zoo nets are built (policy.py:23-91 and :94-199); the LSTM one keeps a per-env recurrent state on the device.
 The ``.npy`` files are loaded with ``numpy.load(allow_pickle=False)``.
 """
 import numpy as np
@@ -173,9 +173,138 @@ class ZooMLPPolicy(object):
         return self._ret(self.evaluate(observation, ppo_capi.FWD_PI, given_action=given_action)["neglogp"], self._np(observation))
 
 
-def load_zoo_policy(path, ac_dim, device=0):
-    """utils.py:66-67 ``load_params`` + MLPPolicy construction."""
+# TF variable-creation order of LSTMPolicy(hiddens=[E, H], normalize=True) -- policy.py:106-183
+_ZOO_LSTM_ORDER = ["retfilter/sum", "retfilter/sumsq", "retfilter/count", "obsfilter/sum", "obsfilter/sumsq", "obsfilter/count",
+                   "v/emb/w", "v/emb/b", "lstmv/kernel", "lstmv/bias", "v/out/w", "v/out/b",
+                   "p/emb/w", "p/emb/b", "lstmp/kernel", "lstmp/bias", "p/out/w", "p/out/b", "logstd"]
+
+
+def zoo_lstm_shapes(ob_dim, ac_dim, emb=HIDDEN, hidden=HIDDEN):
+    e, h = emb, hidden
+    return {"retfilter/sum": (), "retfilter/sumsq": (), "retfilter/count": (),
+            "obsfilter/sum": (ob_dim,), "obsfilter/sumsq": (ob_dim,), "obsfilter/count": (),
+            "v/emb/w": (ob_dim, e), "v/emb/b": (e,), "lstmv/kernel": (e + h, 4 * h), "lstmv/bias": (4 * h,), "v/out/w": (h, 1), "v/out/b": (1,),
+            "p/emb/w": (ob_dim, e), "p/emb/b": (e,), "lstmp/kernel": (e + h, 4 * h), "lstmp/bias": (4 * h,), "p/out/w": (h, ac_dim),
+            "p/out/b": (ac_dim,), "logstd": (1, ac_dim)}
+
+
+def zoo_lstm_param_count(ob_dim, ac_dim, emb=HIDDEN, hidden=HIDDEN):
+    return int(sum(int(np.prod(s)) for s in zoo_lstm_shapes(ob_dim, ac_dim, emb, hidden).values()))
+
+
+def split_zoo_lstm(flat, ac_dim, emb=HIDDEN, hidden=HIDDEN):
+    flat = np.asarray(flat, np.float32).ravel()
+    c0, c1 = zoo_lstm_param_count(0, ac_dim, emb, hidden), zoo_lstm_param_count(1, ac_dim, emb, hidden)
+    ob_dim, r = divmod(flat.size - c0, c1 - c0)
+    if r != 0 or ob_dim <= 0:
+        raise ValueError("%d parameters do not fit a zoo LSTM policy with %d actions" % (flat.size, ac_dim))
+    shapes = zoo_lstm_shapes(int(ob_dim), ac_dim, emb, hidden)
+    out, o = {}, 0
+    for k in _ZOO_LSTM_ORDER:
+        n = int(np.prod(shapes[k]))
+        out[k] = flat[o:o + n].reshape(shapes[k]).copy()
+        o += n
+    return int(ob_dim), out
+
+
+class ZooLSTMPolicy(object):
+    """policy.py:94-199 on the device: observation filter -> relu embedding (64) -> BasicLSTMCell(64) -> head, separately
+    for the value and the policy (two cells).  The recurrent state of every env lives in ``self.state`` ([4][n][64]:
+    value c, value h, policy c, policy h -- the reference's ``zero_state`` order); ``reset(mask)`` zeroes the rows of
+    finished episodes (the reference calls ``policy.reset()`` when an episode starts)."""
+
+    recurrent = True
+
+    def __init__(self, flat_params, ac_dim, device=0, emb=HIDDEN, hidden=HIDDEN):
+        import torch
+        self._t = torch
+        self.device = torch.device("cuda", int(device)) if not isinstance(device, torch.device) else device
+        self.ac_dim, self.emb, self.hidden = int(ac_dim), int(emb), int(hidden)
+        self.ob_dim, p = split_zoo_lstm(flat_params, ac_dim, emb, hidden)
+        self.tensors = p
+        mean, std = filter_stats(p, "obsfilter")
+        self.ret_mean, self.ret_std = [float(x) for x in filter_stats(p, "retfilter")]
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.device)
+        self.dev = {k: dev(v) for k, v in p.items() if "/" in k and not k.startswith(("retfilter", "obsfilter"))}
+        self.dev["logstd"] = dev(p["logstd"])
+        self.obs_mean, self.obs_invstd = dev(mean), dev(np.float32(1.0) / std)
+        self.gen = torch.Generator(device=self.device)
+        self.state = None
+        self._nets = {}
+        for br, cell, head in (("v", "lstmv", None), ("p", "lstmp", "p/out")):
+            n = ppo_capi.LstmNet()
+            n.ob_dim, n.emb_dim, n.hidden, n.ac_dim = self.ob_dim, self.emb, self.hidden, self.ac_dim
+            n.gate_order, n.forget_bias = ppo_capi.LSTM_GATES_IJFO, 1.0          # tf BasicLSTMCell: (i, j, f, o), forget_bias 1
+            n.obs_mean, n.obs_invstd, n.obs_clip = self.obs_mean.data_ptr(), self.obs_invstd.data_ptr(), 5.0
+            n.emb_w, n.emb_b = self.dev[br + "/emb/w"].data_ptr(), self.dev[br + "/emb/b"].data_ptr()
+            k = self.dev[cell + "/kernel"]
+            n.wx, n.wh, n.b = k.data_ptr(), k.data_ptr() + 4 * self.emb * 4 * self.hidden, self.dev[cell + "/bias"].data_ptr()
+            if head:
+                n.head_w, n.head_b, n.logstd = self.dev["p/out/w"].data_ptr(), self.dev["p/out/b"].data_ptr(), self.dev["logstd"].data_ptr()
+            else:
+                n.vf_w, n.vf_b = self.dev["v/out/w"].data_ptr(), self.dev["v/out/b"].data_ptr()
+            self._nets[br] = n
+
+    def seed(self, s):
+        self.gen.manual_seed(int(s))
+
+    def reset(self, mask=None, **kwargs):
+        """policy.py:198-199; ``mask`` (bool / uint8 [n], host or device) restricts the reset to those rows."""
+        if self.state is None:
+            return
+        if mask is None:
+            self.state.zero_()
+        else:
+            m = self._t.as_tensor(mask, device=self.device).to(self._t.bool)
+            self.state[:, m, :] = 0.0
+
+    def act(self, observation, stochastic=True, want_value=False):
+        t = self._t
+        np_in = isinstance(observation, np.ndarray) or not t.is_tensor(observation)
+        x = observation
+        single = False
+        if np_in:
+            x = np.asarray(x, np.float32)
+            single = x.ndim == 1
+            x = t.from_numpy(np.ascontiguousarray(x[None] if single else x)).to(self.device)
+        if x.dtype != t.float32 or x.dim() != 2 or x.stride(1) != 1 or x.shape[1] < self.ob_dim:
+            raise ValueError("expected float32 [n, >=%d] observations with unit inner stride" % self.ob_dim)
+        n, A, H = x.shape[0], self.ac_dim, self.hidden
+        if self.state is None or self.state.shape[1] != n:
+            self.state = t.zeros((4, n, H), dtype=t.float32, device=self.device)
+        action = t.empty((n, A), dtype=t.float32, device=self.device)
+        noise = t.randn((n, A), generator=self.gen, device=self.device, dtype=t.float32) if stochastic else None
+        st = t.cuda.current_stream(self.device).cuda_stream
+        stride = x.stride(0) if n > 1 else x.shape[1]
+        L = ppo_capi.lib()
+        import ctypes as C
+        ppo_capi.chk(L.ppo_lstm_step(C.byref(self._nets["p"]), x.data_ptr(), n, stride, None, self.state[2].data_ptr(),
+                                     self.state[3].data_ptr(), H, ppo_capi.ptr(noise), None, action.data_ptr(), None, None, None, st))
+        info = {"state": self.state}
+        if want_value:
+            value = t.empty(n, dtype=t.float32, device=self.device)
+            ppo_capi.chk(L.ppo_lstm_step(C.byref(self._nets["v"]), x.data_ptr(), n, stride, None, self.state[0].data_ptr(),
+                                         self.state[1].data_ptr(), H, None, None, None, None, value.data_ptr(), None, st))
+            value = value * self.ret_std + self.ret_mean
+            info["vpred"] = value.cpu().numpy() if np_in else value
+            if single:
+                info["vpred"] = info["vpred"][0]
+        a = action.cpu().numpy() if np_in else action
+        return (a[0] if single else a), info
+
+
+def load_zoo_policy(path, ac_dim, device=0, kind=None):
+    """utils.py:66-67 ``load_params`` + policy construction; ``kind`` 'mlp' / 'lstm' (default: whichever layout fits the
+    vector length)."""
     flat = np.load(path, allow_pickle=False)
+    if kind is None:
+        try:
+            infer_ob_dim(flat.size, ac_dim)
+            kind = "mlp"
+        except ValueError:
+            kind = "lstm"
+    if kind == "lstm":
+        return ZooLSTMPolicy(flat, ac_dim, device=device)
     return ZooMLPPolicy(flat, ac_dim, device=device)
 
 
@@ -214,6 +343,8 @@ def evaluate_against(model, opponent, env, rounds, deterministic=True):
         steps += 1
         fin = done[:, 0] != 0
         nfin = int(fin.sum())
+        if nfin and getattr(opponent, "recurrent", False):
+            opponent.reset(fin)
         if nfin:
             flags = info[:, :, 7].to(torch.int64)
             w0 = ((flags[:, 0] & 1) != 0) & fin

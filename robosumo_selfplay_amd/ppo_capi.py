@@ -6,14 +6,23 @@ from . import build as _build
 
 NSTATS = 8
 FWD_PI, FWD_VF, FWD_TANH = 1, 2, 4
+LSTM_GATES_IFOU, LSTM_GATES_IJFO = 0, 1
 _LIB = None
 
-EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_forward_filtered", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
+EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_forward_filtered", "ppo_lstm_step", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
            "ppo_adv_normalize", "ppo_grad_workspace_bytes", "ppo_grad", "ppo_clip_adam")
 
 
 class PpoHipError(RuntimeError):
     pass
+
+
+class LstmNet(C.Structure):
+    """``ppo_lstm_net`` of include/sumo_ppo.h (device pointers as integers; 0 / None = absent)."""
+    _fields_ = [("ob_dim", C.c_int), ("emb_dim", C.c_int), ("hidden", C.c_int), ("ac_dim", C.c_int), ("gate_order", C.c_int),
+                ("forget_bias", C.c_float), ("obs_mean", C.c_void_p), ("obs_invstd", C.c_void_p), ("obs_clip", C.c_float),
+                ("emb_w", C.c_void_p), ("emb_b", C.c_void_p), ("wx", C.c_void_p), ("wh", C.c_void_p), ("b", C.c_void_p),
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("logstd", C.c_void_p), ("vf_w", C.c_void_p), ("vf_b", C.c_void_p)]
 
 
 def lib():
@@ -28,6 +37,7 @@ def lib():
         L.ppo_param_count.argtypes = [i32, i32]
         L.ppo_forward.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.ppo_forward_filtered.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
+        L.ppo_lstm_step.argtypes = [C.POINTER(LstmNet), vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
         L.ppo_reward_mix.argtypes = [vp, i32, f64, vp, i32, vp]
         L.ppo_vtrace.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp, vp]
         L.ppo_adv_moments.argtypes = [vp, vp, vp, i32, vp, vp]

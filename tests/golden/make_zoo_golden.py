@@ -23,4 +23,16 @@ for kind, ac in AC.items():
             obs_mean_first4=[float(x) for x in mean[:4]], obs_std_first4=[float(x) for x in std[:4]],
             polfinal_b=[float(x) for x in p["polfinal/b"].ravel()[:4]])
 json.dump(out, open(os.path.join(os.path.dirname(__file__), "zoo_mlp_layout.json"), "w"), indent=1)
+lout = {}
+for kind, ac in AC.items():
+    for v in (1, 2, 3):
+        flat = np.load(os.path.join(ROOT, kind, "lstm", "agent-params-v%d.npy" % v), allow_pickle=False)
+        ob_dim, p = policy_zoo.split_zoo_lstm(flat, ac)
+        lout["%s-v%d" % (kind, v)] = dict(
+            nparams=int(flat.size), dtype=str(flat.dtype), ac_dim=ac, ob_dim=ob_dim,
+            obs_count=float(p["obsfilter/count"]), ret_count=float(p["retfilter/count"]),
+            logstd=[float(x) for x in p["logstd"].ravel()], tail=[float(x) for x in flat[-4:]],
+            lstmp_bias_absmax=float(np.abs(p["lstmp/bias"]).max()), p_out_b=[float(x) for x in p["p/out/b"].ravel()[:4]])
+json.dump(lout, open(os.path.join(os.path.dirname(__file__), "zoo_lstm_layout.json"), "w"), indent=1)
+print(json.dumps({k: (v["nparams"], v["ob_dim"], v["obs_count"], v["logstd"][:2]) for k, v in lout.items()}))
 print(json.dumps({k: (v["nparams"], v["ob_dim"], v["obs_count"], v["logstd"][:3]) for k, v in out.items()}, indent=0))

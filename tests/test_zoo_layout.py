@@ -48,3 +48,27 @@ def test_filter_stats_match_running_mean_std():
     mean, std = policy_zoo.filter_stats(p, "f")
     assert np.allclose(mean, [5.0, -2.0])
     assert np.allclose(std, [np.sqrt(5.0), 0.1])      # second variance (5e-5) is floored at 1e-2
+
+
+LGOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "zoo_lstm_layout.json")))
+
+
+@pytest.mark.parametrize("key", sorted(LGOLD))
+def test_lstm_param_count_matches_shipped_files(key):
+    g = LGOLD[key]
+    m = mjcf.load_model(ENV_OF[key.split("-")[0]])
+    assert g["ob_dim"] == m.obs_dims[0] - 1 and g["ac_dim"] == m.act_dims[0]
+    assert policy_zoo.zoo_lstm_param_count(g["ob_dim"], g["ac_dim"]) == g["nparams"] and g["dtype"] == "float32"
+    assert g["obs_count"] > 1e6 and all(-6.0 < x < 0.5 for x in g["logstd"]) and len(g["logstd"]) == g["ac_dim"]
+    assert g["lstmp_bias_absmax"] < 5.0      # a bias vector, not a weight block, sits where the layout says
+
+
+def test_lstm_split_roundtrip():
+    rng = np.random.default_rng(1)
+    D, A = 164, 12
+    flat = rng.standard_normal(policy_zoo.zoo_lstm_param_count(D, A)).astype(np.float32)
+    ob_dim, p = policy_zoo.split_zoo_lstm(flat, A)
+    assert ob_dim == D and p["lstmv/kernel"].shape == (128, 256) and p["p/out/w"].shape == (64, A)
+    assert np.array_equal(np.concatenate([np.ravel(p[k]) for k in policy_zoo._ZOO_LSTM_ORDER]), flat)
+    with pytest.raises(ValueError):
+        policy_zoo.split_zoo_lstm(flat[:-3], A)
