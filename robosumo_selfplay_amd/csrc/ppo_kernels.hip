@@ -746,27 +746,52 @@ __global__ void __launch_bounds__(256) ppo_grad_kernel(GradArgs a) {
   else grad_net<KT, false>(a, lds, wave_global, lane);
 }
 
-// grads[p] = sum over waves of the slab of the net that owns p (fixed order); stats += per-wave stats
-__global__ void ppo_grad_reduce_kernel(const float* slabs, const double* wstats, int nwaves, ParamLayout L, float* grads, double* stats) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
+// grads[p] = sum over waves of the slab of the net that owns p; stats += per-wave stats.  Two passes so that the 100 MB of
+// slabs (one per wave) are streamed by thousands of workgroups instead of P threads: groups of RED_GROUP consecutive slabs
+// are summed in order into partial[g][p], then the partials in order -- a fixed association, hence deterministic.
+#define RED_GROUP 16
+__global__ void __launch_bounds__(256) ppo_grad_reduce1_kernel(const float* slabs, int nwaves, ParamLayout L, float* partial) {
+  const int p = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+  if (p >= L.P) return;
+  const bool is_vf = (p >= L.vf_w0 && p < L.pi_w) || p >= L.vf_w;
+  const float* s = slabs + (size_t)(is_vf ? 1 : 0) * nwaves * L.P + p;
+  const int w0 = g * RED_GROUP, w1 = w0 + RED_GROUP < nwaves ? w0 + RED_GROUP : nwaves;
+  float v[RED_GROUP];
+#pragma unroll
+  for (int k = 0; k < RED_GROUP; k++) v[k] = w0 + k < w1 ? s[(size_t)(w0 + k) * L.P] : 0.0f;   // all loads in flight
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < RED_GROUP; k++) acc += v[k];
+  partial[(size_t)g * L.P + p] = acc;
+}
+__global__ void __launch_bounds__(256) ppo_grad_reduce2_kernel(const float* partial, int G, const double* wstats, int nwaves, ParamLayout L,
+                                                               float* grads, double* stats) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
   if (p < L.P) {
-    bool is_vf = (p >= L.vf_w0 && p < L.pi_w) || p >= L.vf_w;
-    const float* s = slabs + (size_t)(is_vf ? 1 : 0) * nwaves * L.P + p;
     float acc = 0.0f;
-    for (int w = 0; w < nwaves; w++) acc += s[(size_t)w * L.P];
+    for (int g = 0; g < G; g++) acc += partial[(size_t)g * L.P + p];
     grads[p] = acc;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 8) {
+  if (blockIdx.x == 0) {   // 8 statistics x 2*nwaves entries: 32 chunks per statistic in parallel, then the chunks in order
+    __shared__ double chunk[32][8];
+    const int k = threadIdx.x & 7, c = threadIdx.x >> 3, n = 2 * nwaves, per = (n + 31) / 32;
     double acc = 0;
-    for (int w = 0; w < 2 * nwaves; w++) acc += wstats[(size_t)w * 8 + threadIdx.x];
-    stats[threadIdx.x] += acc;
+    for (int w = c * per; w < (c + 1) * per && w < n; w++) acc += wstats[(size_t)w * 8 + k];
+    chunk[c][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      double t = 0;
+      for (int q = 0; q < 32; q++) t += chunk[q][threadIdx.x];
+      stats[threadIdx.x] += t;
+    }
   }
 }
 
 static int grad_nwaves(void) { return 256 * 4; }
 extern "C" size_t ppo_grad_workspace_bytes(int ob_dim, int ac_dim) {
   ParamLayout L = make_layout(ob_dim, ac_dim);
-  return (size_t)2 * grad_nwaves() * L.P * sizeof(float) + (size_t)2 * grad_nwaves() * 8 * sizeof(double);
+  return (size_t)2 * grad_nwaves() * L.P * sizeof(float) + (size_t)2 * grad_nwaves() * 8 * sizeof(double) +
+         (size_t)(grad_nwaves() / RED_GROUP) * L.P * sizeof(float);   // slabs | per-wave stats | partial sums
 }
 
 extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, int ob_dim, int ac_dim, const float* actions,
@@ -805,7 +830,12 @@ extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, i
   else LAUNCH(14);
 #undef LAUNCH
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3((a.L.P + 255) / 256), dim3(256), 0, s, a.slabs, a.wstats, a.nwaves, a.L, grads, stats);
+  {
+    float* partial = (float*)((char*)workspace + (size_t)2 * grad_nwaves() * a.L.P * sizeof(float) + (size_t)2 * grad_nwaves() * 8 * sizeof(double));
+    const int G = (a.nwaves + RED_GROUP - 1) / RED_GROUP;
+    hipLaunchKernelGGL(ppo_grad_reduce1_kernel, dim3((a.L.P + 255) / 256, G), dim3(256), 0, s, a.slabs, a.nwaves, a.L, partial);
+    hipLaunchKernelGGL(ppo_grad_reduce2_kernel, dim3((a.L.P + 255) / 256), dim3(256), 0, s, partial, G, a.wstats, a.nwaves, a.L, grads, stats);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

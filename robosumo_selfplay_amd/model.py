@@ -43,6 +43,7 @@ class PPOModel(object):
             self.stats = torch.zeros(ppo_capi.NSTATS, dtype=torch.float64, device=self.device)
             self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
             self.workspace = torch.empty(ppo_capi.lib().ppo_grad_workspace_bytes(D, A), dtype=torch.uint8, device=self.device)
+            self._graphs = {}
 
     # ---- checkpoints: list of 13 float32 arrays in TF variable order (model.py:153-177) -----------------------
     def get_param_list(self):
@@ -89,6 +90,69 @@ class PPOModel(object):
             return [np.float32(s) for s in stats] + [out[5].cpu().numpy(), None]
         return list(stats) + [out[5], None]
 
+    # The launch-bound inner loop (noptepochs x nminibatches optimiser steps of ~7 small launches + tensor bookkeeping each)
+    # is captured once per (batch arrays, minibatch size, cliprange) into a HIP graph and replayed with a fresh index
+    # vector; only the Adam step stays outside (its step count is a host scalar).  Single-GPU, asynchronous path only.
+    use_graph = os.environ.get("SUMO_PPO_GRAPH", "1") != "0"
+
+    def _launch_loss_grad(self, obs, returns, actions, values, neglogpacs, weights, idx, n, cliprange, adv, log_ratio, st):
+        L = ppo_capi.lib()
+        D, A = self.spec.ob_dim, self.spec.ac_dim
+        ip = idx.data_ptr()
+        ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), st))
+        ppo_capi.chk(L.ppo_adv_normalize(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), adv.data_ptr(), st))
+        self.stats.zero_()
+        ppo_capi.chk(L.ppo_grad(self.params.data_ptr(), obs.data_ptr(), obs.stride(0), D, A, actions.data_ptr(), adv.data_ptr(),
+                                returns.data_ptr(), neglogpacs.data_ptr(), weights.data_ptr(), ip, n, 1.0 / float(n),
+                                float(cliprange), self.ent_coef, self.vf_coef, self.grads.data_ptr(), self.stats.data_ptr(),
+                                log_ratio.data_ptr(), self.workspace.data_ptr(), st))
+
+    def _graph_step(self, lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n):
+        t = self._t
+        A = self.spec.ac_dim
+        key = (obs.data_ptr(), obs.stride(0), returns.data_ptr(), actions.data_ptr(), values.data_ptr(), neglogpacs.data_ptr(),
+               weights.data_ptr(), int(n), float(cliprange))
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 2:
+                self._graphs.clear()
+            try:
+                ent = dict(idx=t.zeros(n, dtype=t.int32, device=self.device), adv=t.empty(n, dtype=t.float32, device=self.device),
+                           log_ratio=t.empty(n, dtype=t.float32, device=self.device), keep=(obs, returns, actions, values, neglogpacs, weights))
+                side = t.cuda.Stream(device=self.device)
+                side.wait_stream(t.cuda.current_stream(self.device))
+                with t.cuda.stream(side):       # warm-up outside the capture (one-time kernel attributes, allocator)
+                    ent["idx"].copy_(idx)
+                    self._launch_loss_grad(obs, returns, actions, values, neglogpacs, weights, ent["idx"], n, cliprange, ent["adv"],
+                                           ent["log_ratio"], side.cuda_stream)
+                t.cuda.current_stream(self.device).wait_stream(side)
+                t.cuda.synchronize(self.device)
+                graph = t.cuda.CUDAGraph()
+                with t.cuda.graph(graph):
+                    cst = t.cuda.current_stream(self.device).cuda_stream
+                    self._launch_loss_grad(obs, returns, actions, values, neglogpacs, weights, ent["idx"], n, cliprange, ent["adv"],
+                                           ent["log_ratio"], cst)
+                    logstd = self.params[self.P - 1 - policies.HIDDEN - A:self.P - 1 - policies.HIDDEN]
+                    entropy_t = (logstd.double() + 0.5 * np.log(2.0 * np.pi * np.e)).sum()
+                    sst = self.stats
+                    ent["out"] = t.stack([sst[0] / sst[6], sst[1] / sst[6], entropy_t, sst[3] / sst[6], sst[4] / sst[6]])
+                ent["graph"] = graph
+                g = self._graphs[key] = ent
+            except Exception as e:                     # capture unsupported here: stay on the eager path for good
+                type(self).use_graph = False
+                self._graphs.clear()
+                import warnings
+                warnings.warn("HIP graph capture of the PPO step failed (%r); using eager launches" % (e,))
+                return None
+        g["idx"].copy_(idx)
+        g["graph"].replay()
+        self.t += 1
+        ppo_capi.chk(ppo_capi.lib().ppo_clip_adam(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                                   self.P, self.t, float(lr), 0.9, 0.999, 1e-5,
+                                                   float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0,
+                                                   self.stats.data_ptr(), t.cuda.current_stream(self.device).cuda_stream))
+        return g["out"].clone()
+
     def train_indexed(self, lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n, sync=True):
         """One optimiser step on rows ``idx`` (int32 CUDA tensor or None) of device-resident batch arrays.
         ``sync=False`` skips the host read-back of the loss statistics (returns a device tensor
@@ -98,10 +162,14 @@ class PPOModel(object):
         t = self._t
         L = ppo_capi.lib()
         D, A = self.spec.ob_dim, self.spec.ac_dim
-        st = t.cuda.current_stream(self.device).cuda_stream
-        ip = ppo_capi.ptr(idx)
         if obs.stride(1) != 1:
             raise ValueError("obs rows must have unit inner stride")
+        if not sync and self.comm is None and idx is not None and self.use_graph:
+            out = self._graph_step(lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n)
+            if out is not None:
+                return out
+        st = t.cuda.current_stream(self.device).cuda_stream
+        ip = ppo_capi.ptr(idx)
         # advantages: returns - values, normalised over the (global) minibatch (model.py:180-185)
         ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), st))
         sdist.allreduce_moments(self.moments, self.comm)

@@ -296,3 +296,30 @@ def test_learn_opponent_modes_and_opponent_data(tmp_path):
     assert len(model.history["lossvals"]) == 3 and all(np.isfinite(l).all() for l in model.history["lossvals"])
     assert len(os.listdir(os.path.join(str(tmp_path), "checkpoints"))) == 4
     env.close()
+
+
+def test_graph_replay_matches_eager_steps():
+    """The HIP-graph path of train_indexed (asynchronous, single GPU) replays exactly the eager launches."""
+    rng = np.random.default_rng(3)
+    D, A, nb, n = 121, 8, 4096, 512
+    obs = torch.from_numpy(rng.standard_normal((nb, D)).astype(np.float32)).to(DEV)
+    act = torch.from_numpy(rng.standard_normal((nb, A)).astype(np.float32)).to(DEV)
+    ret = torch.from_numpy(rng.standard_normal(nb).astype(np.float32)).to(DEV)
+    val = torch.from_numpy(rng.standard_normal(nb).astype(np.float32)).to(DEV)
+    w = torch.ones(nb, dtype=torch.float32, device=DEV)
+    res = []
+    for use_graph in (False, True):
+        m = _model(D, A, seed=5)
+        m.use_graph = use_graph
+        nlp = m.act_model.action_probability(obs, given_action=act) + 0.05
+        outs = []
+        r2 = np.random.default_rng(9)
+        for k in range(6):
+            idx = torch.from_numpy(r2.permutation(nb)[:n].astype(np.int32)).to(DEV)
+            outs.append(m.train_indexed(1e-3, 0.2, obs, ret, act, val, nlp, w, idx, n, sync=False))
+        torch.cuda.synchronize()
+        assert (len(m._graphs) == 1) == use_graph
+        res.append((m.params.clone(), torch.stack(outs).cpu().numpy(), m.t))
+    assert res[0][2] == res[1][2] == 6
+    assert torch.equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
