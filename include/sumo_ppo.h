@@ -79,6 +79,26 @@ int ppo_lstm_step(const ppo_lstm_net* net, const float* obs, int n, int obs_stri
                   int state_stride, const float* noise, const float* given_action, float* action_out, float* neglogp_out,
                   float* value_out, float* mean_out, void* stream);
 
+/* --- recurrent training (back-propagation through time over the baselines LSTM; the reference builds the unrolled graph in
+ * a2c/utils.py:82-103 + model.py:65-139, its own recurrent minibatch loop alg_ppo.py:408-421 is dead code) ---------------
+ * ppo_lstm_step_save: ppo_lstm_step that also records what the backward pass needs for this time step:
+ *   save_gates [n][4*hidden] activated gates in the net's column order, save_cprev / save_hprev [n][hidden] the masked
+ *   previous state, save_tanhc [n][hidden] tanh of the new cell state (the new h is the latent: read it from `h`). */
+int ppo_lstm_step_save(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
+                       int state_stride, float* save_gates, float* save_cprev, float* save_hprev, float* save_tanhc, void* stream);
+/* PPO loss heads on stored latents (rows = all (time, env) pairs of the minibatch): forward of the Gaussian / value heads,
+ * loss terms of model.py:65-111 and their gradients.  Outputs: dlatent [rows][hidden], dmean [rows][ac_dim], dvalue [rows],
+ * dlogstd_rows [rows][ac_dim] (sum over rows - ent_coef = d loss / d logstd), stats double[PPO_NSTATS] (+= un-normalised sums
+ * as ppo_grad; stats[2] is not touched).  inv_count = 1 / (global number of rows). */
+int ppo_lstm_head_grad(const ppo_lstm_net* net, const float* latent, int rows, const float* actions, const float* adv,
+                       const float* returns, const float* old_neglogp, const float* is_weight, double inv_count, float cliprange,
+                       float vf_coef, float* dlatent, float* dmean, float* dvalue, float* dlogstd_rows, double* stats, void* stream);
+/* One step of BPTT (gate order i,f,o,u): dh_carry / dc_carry [n][hidden] hold d loss / d (h_t, c_t) flowing from later steps and
+ * are replaced by the values for step t-1 (already multiplied by 1 - mask_t); dz_out [n][4*hidden] receives d loss / d
+ * (pre-activation gates), whose products with the inputs give the weight gradients (plain GEMMs, done by the caller). */
+int ppo_lstm_bwd_step(const ppo_lstm_net* net, int n, const float* dlatent_t, const float* mask_t, const float* gates_t,
+                      const float* cprev_t, const float* tanhc_t, float* dh_carry, float* dc_carry, float* dz_out, void* stream);
+
 /* info float64 [n][2][8] as written by sumo_step (slot 6 shaping, slot 3 main); reward_out float32 [2][n]
  * (agent-major, one time slice of the rollout buffer) = alpha*shaping + (1-alpha)*main evaluated in float64. */
 int ppo_reward_mix(const double* info, int n, double alpha, float* reward_out, int agent_stride, void* stream);

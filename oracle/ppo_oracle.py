@@ -360,3 +360,76 @@ def zoo_lstm_step(p, obs, state):
     pc, ph = basic_lstm_cell(p["lstmp/kernel"], p["lstmp/bias"], ep, state[2], state[3])
     mean = ph @ p["p/out/w"] + p["p/out/b"]
     return mean.astype(np.float32), vpred.astype(np.float32), np.stack([vc, vh, pc, ph])
+
+
+def lstm_ppo_loss_and_grads(params, obs, masks, actions, advs, returns, oldneglogp, is_weight, S0, cliprange, ent_coef, vf_coef,
+                            dtype=np.float64):
+    """PPO loss of model.py:65-111 over a recurrent policy (baselines lstm, shared latent: models.py:131-183,
+    policies.py:160-181) unrolled over time, and its gradient by back-propagation through time.
+    params = [wx, wh, b, pi_w, pi_b, logstd(1,A), vf_w, vf_b]; obs [T,n,D]; masks [T,n] (done before step t); actions
+    [T,n,A]; advs / returns / oldneglogp / is_weight [T,n]; S0 [n, 2H] = (c | h) at the start of the sequence.
+    Returns (loss, stats[5], grads list, final state)."""
+    wx, wh, b, pw, pb, logstd, vw, vb = [np.asarray(x, dtype) for x in params]
+    obs, masks, A_ = np.asarray(obs, dtype), np.asarray(masks, dtype), np.asarray(actions, dtype)
+    adv, R, old, w = (np.asarray(v, dtype) for v in (advs, returns, oldneglogp, is_weight))
+    T, n, _ = obs.shape
+    H = wh.shape[0]
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+    c, h = np.asarray(S0[:, :H], dtype).copy(), np.asarray(S0[:, H:], dtype).copy()
+    cache = []
+    lat = np.zeros((T, n, H), dtype)
+    for t in range(T):
+        m = masks[t][:, None]
+        cp, hp = c * (1 - m), h * (1 - m)
+        z = obs[t] @ wx + hp @ wh + b
+        i, f, o, u = sig(z[:, :H]), sig(z[:, H:2 * H]), sig(z[:, 2 * H:3 * H]), np.tanh(z[:, 3 * H:])
+        c = f * cp + i * u
+        tc = np.tanh(c)
+        h = o * tc
+        cache.append((cp, hp, i, f, o, u, tc))
+        lat[t] = h
+    N = T * n
+    L = lat.reshape(N, H)
+    mean = L @ pw + pb
+    value = (L @ vw + vb)[:, 0]
+    Af, advf, Rf, oldf, wf = A_.reshape(N, -1), adv.reshape(N), R.reshape(N), old.reshape(N), w.reshape(N)
+    std = np.exp(logstd)
+    nlp = neglogp(mean, logstd, Af)
+    ent = np.sum(logstd + 0.5 * np.log(2.0 * np.pi * np.e))
+    vf_loss = 0.5 * np.mean(np.square(value - Rf))
+    ratio = np.exp(oldf - nlp)
+    nanmask = np.isnan(ratio)
+    ratio = np.where(nanmask, 2.0, ratio)
+    l1 = -advf * ratio
+    l2 = -advf * np.clip(ratio, 1.0 - cliprange, 1.0 + cliprange)
+    pg_loss = np.mean(wf * np.maximum(l1, l2))
+    approxkl = np.mean(nlp - oldf)
+    clipfrac = np.mean((np.abs(ratio - 1.0) > cliprange).astype(dtype))
+    loss = pg_loss - ent * ent_coef + vf_loss * vf_coef
+    in_clip = (ratio >= 1.0 - cliprange) & (ratio <= 1.0 + cliprange)
+    d_l1 = (l1 >= l2).astype(dtype)
+    dratio = np.where(nanmask, 0.0, wf / N * (d_l1 * (-advf) + (1.0 - d_l1) * (-advf) * in_clip))
+    dnlp = -dratio * ratio
+    zz = (Af - mean) / std
+    dmean = dnlp[:, None] * (-(zz / std))
+    dlogstd = np.sum(dnlp[:, None] * (1.0 - zz * zz), axis=0, keepdims=True) - ent_coef * np.ones_like(logstd)
+    dvalue = vf_coef * (value - Rf) / N
+    g_pw, g_pb = L.T @ dmean, dmean.sum(0)
+    g_vw, g_vb = L.T @ dvalue[:, None], np.array([dvalue.sum()])
+    dlat = (dmean @ pw.T + dvalue[:, None] @ vw.T).reshape(T, n, H)
+    g_wx, g_wh, g_b = np.zeros_like(wx), np.zeros_like(wh), np.zeros_like(b)
+    dh, dc = np.zeros((n, H), dtype), np.zeros((n, H), dtype)
+    for t in range(T - 1, -1, -1):
+        cp, hp, i, f, o, u, tc = cache[t]
+        dht = dlat[t] + dh
+        do = dht * tc
+        dct = dc + dht * o * (1.0 - tc * tc)
+        dz = np.concatenate([dct * u * i * (1 - i), dct * cp * f * (1 - f), do * o * (1 - o), dct * i * (1 - u * u)], axis=1)
+        g_wx += obs[t].T @ dz
+        g_wh += hp.T @ dz
+        g_b += dz.sum(0)
+        m = masks[t][:, None]
+        dh = (dz @ wh.T) * (1 - m)
+        dc = dct * f * (1 - m)
+    stats = np.array([pg_loss, vf_loss, ent, approxkl, clipfrac])
+    return loss, stats, [g_wx, g_wh, g_b, g_pw, g_pb, dlogstd, g_vw, g_vb], np.concatenate([c, h], axis=1)

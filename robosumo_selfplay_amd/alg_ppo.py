@@ -56,13 +56,20 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
     ob_space, ac_space = env.observation_space[0], env.action_space[0]
     nbatch = nenvs * nsteps
     nbatch_train = nbatch // nminibatches
-    model_fn = model_fn or PPOModel
+    recurrent = network == "lstm"
+    if recurrent:
+        from .lstm_model import LstmPPOModel
+        if use_opponent_data is not None or comm is not None:
+            raise NotImplementedError("recurrent policies: no opponent-data reuse, single GPU")
+        assert nenvs % nminibatches == 0, "recurrent minibatches are whole env sequences: nenvs %% nminibatches must be 0"
+    model_fn = model_fn or (LstmPPOModel if recurrent else PPOModel)
     dev = getattr(env, "device", torch.device("cuda", 0))
-    mk = lambda scope, trainable: model_fn(policy=policy, ob_space=ob_space, ac_space=ac_space, nbatch_act=None,
+    mk = lambda scope, trainable: model_fn(policy=policy, ob_space=ob_space, ac_space=ac_space, nbatch_act=nenvs,
                                            nbatch_train=nbatch_train, nsteps=nsteps, ent_coef=ent_coef, vf_coef=vf_coef,
                                            max_grad_norm=max_grad_norm, trainable=trainable, model_scope=scope, device=dev.index or 0,
                                            comm=comm if trainable else None)
     model = mk("model_0", True)
+    model.equal_counts = use_opponent_data is None      # opponent-data reuse makes per-rank minibatch sizes differ
     sdist.broadcast_params(model.params, comm)                          # sync_from_root (ppo2/model.py:129-131)
     models = [model] + [mk("model_%d" % i, False) for i in range(1, nagent)]
     model_util = mk("model_util", False)
@@ -137,6 +144,11 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         torch.cuda.synchronize(dev)
         t_roll = time.perf_counter() - tstart
         T, N = nsteps, nenvs
+        if isinstance(obs, np.ndarray):       # host-mode Runner (recurrent models): continue on the device like the MLP path
+            up = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(dev)
+            obs, returns, masks, actions, values, neglogpacs, rewards, opponent_neglogpacs = map(
+                up, (obs, returns, masks, actions, values, neglogpacs, rewards, opponent_neglogpacs))
+            off_policy_ratio, off_env_ratio, total_ratio = map(up, (off_policy_ratio, off_env_ratio, total_ratio))
         # un-scrambled opponent data for the 'ours' selector: rows = agent 1's (obs, action), env-major
         opponent_obs, opponent_actions = obs[1], actions[1]
         # ---- ratio hygiene (alg_ppo.py:258-280)
@@ -171,7 +183,21 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         # ---- minibatch SGD (alg_ppo.py:355-398)
         nsamp = b_obs.shape[0]
         mblossvals, early_stop, stop_info = [], False, None
-        for epoch in range(noptepochs):
+        if recurrent:                          # baselines ppo2 recurrent convention: minibatches of whole env sequences
+            envsperbatch = nenvs // nminibatches
+            envinds = np.arange(nenvs)
+            flatinds = np.arange(nenvs * nsteps).reshape(nenvs, nsteps)
+            st0 = torch.as_tensor(np.asarray(states, np.float32)).to(dev)
+            b_masks = masks[0]
+            for epoch in range(noptepochs):
+                np.random.shuffle(envinds)
+                for start in range(0, nenvs, envsperbatch):
+                    mbenv = envinds[start:start + envsperbatch]
+                    mbflat = torch.from_numpy(flatinds[mbenv].ravel()).to(dev)
+                    out = model.train(lrnow, cliprangenow, b_obs[mbflat], b_ret[mbflat], b_masks[mbflat], b_act[mbflat], b_val[mbflat],
+                                      b_nlp[mbflat], None, weights[mbflat], st0[torch.from_numpy(mbenv).to(dev)], nsteps=nsteps)
+                    mblossvals.append(torch.tensor([float(x) for x in out[:5]], dtype=torch.float64))
+        for epoch in range(noptepochs if not recurrent else 0):
             inds = torch.from_numpy(np.random.permutation(nsamp).astype(np.int32)).to(dev)    # np.random.shuffle (:375)
             for ii, start in enumerate(range(0, nsamp, nbatch_train)):
                 mb = inds[start:start + nbatch_train]
@@ -185,7 +211,7 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
             if early_stop:
                 break
         history["early_stop_info"].append(stop_info)
-        if kl_threshold is None:
+        if kl_threshold is None or recurrent:
             lossvals = torch.stack(mblossvals).mean(dim=0).cpu().numpy().astype(np.float64)
         else:
             lossvals = np.mean(np.array(mblossvals, dtype=np.float64), axis=0)

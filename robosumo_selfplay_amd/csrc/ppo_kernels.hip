@@ -256,6 +256,7 @@ struct LstmArgs {
   ppo_lstm_net net;
   const float *obs, *mask, *noise, *given;
   float *c, *h, *action, *neglogp, *value, *mean;
+  float *sv_gates, *sv_cprev, *sv_hprev, *sv_tanhc;   // training: per-step records for the backward pass (all or none)
   int n, obs_stride, state_stride, XS, HP;
 };
 
@@ -275,6 +276,7 @@ __global__ void __launch_bounds__(64) ppo_lstm_step_kernel(LstmArgs a) {
     float v = 0.0f;
     if (row < a.n) { v = a.h[(size_t)row * a.state_stride + k]; if (a.mask) v *= 1.0f - a.mask[row]; }
     hprev[r * HP + k] = v;
+    if (a.sv_hprev && row < a.n) a.sv_hprev[(size_t)row * NH + k] = v;
   }
   wave_sync();
   // ---- optional embedding: relu(x * We + be), 64 wide
@@ -338,8 +340,15 @@ __global__ void __launch_bounds__(64) ppo_lstm_step_kernel(LstmArgs a) {
       float cp = 0.0f;
       if (row < a.n) { cp = a.c[(size_t)row * a.state_stride + j]; if (a.mask) cp *= 1.0f - a.mask[row]; }
       const float ig = sigmoidf_(zi[r] + bi), fg = sigmoidf_(zf[r] + bf), og = sigmoidf_(zo[r] + bo), ug = tanhf(zu[r] + bu);
-      const float cn = fg * cp + ig * ug, hn = og * tanhf(cn);
-      if (row < a.n) { a.c[(size_t)row * a.state_stride + j] = cn; a.h[(size_t)row * a.state_stride + j] = hn; }
+      const float cn = fg * cp + ig * ug, tcn = tanhf(cn), hn = og * tcn;
+      if (row < a.n) {
+        a.c[(size_t)row * a.state_stride + j] = cn; a.h[(size_t)row * a.state_stride + j] = hn;
+        if (a.sv_gates) {
+          float* sg = a.sv_gates + (size_t)row * 4 * NH;
+          sg[gi * NH + j] = ig; sg[gf * NH + j] = fg; sg[go * NH + j] = og; sg[gu * NH + j] = ug;
+          a.sv_cprev[(size_t)row * NH + j] = cp; a.sv_tanhc[(size_t)row * NH + j] = tcn;
+        }
+      }
       hnew[(4 * kq + r) * HP + j] = hn;
     }
   }
@@ -378,9 +387,10 @@ __global__ void __launch_bounds__(64) ppo_lstm_step_kernel(LstmArgs a) {
   }
 }
 
-extern "C" int ppo_lstm_step(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
-                             int state_stride, const float* noise, const float* given_action, float* action_out,
-                             float* neglogp_out, float* value_out, float* mean_out, void* stream) {
+static int lstm_launch(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
+                       int state_stride, const float* noise, const float* given_action, float* action_out, float* neglogp_out,
+                       float* value_out, float* mean_out, float* sv_gates, float* sv_cprev, float* sv_hprev, float* sv_tanhc,
+                       void* stream) {
   if (!net || !obs || !c || !h || n <= 0) FAIL(-1, "bad arguments");
   if (net->hidden != 64 && net->hidden != 128) FAIL(-2, "hidden %d: only 64 and 128 are built", net->hidden);
   if (net->ob_dim < 1 || net->ob_dim > 512 || obs_stride < net->ob_dim) FAIL(-3, "bad ob_dim/obs_stride");
@@ -392,6 +402,7 @@ extern "C" int ppo_lstm_step(const ppo_lstm_net* net, const float* obs, int n, i
   LstmArgs a;
   a.net = *net; a.obs = obs; a.mask = mask; a.noise = noise; a.given = given_action; a.c = c; a.h = h; a.action = action_out;
   a.neglogp = neglogp_out; a.value = value_out; a.mean = mean_out; a.n = n; a.obs_stride = obs_stride; a.state_stride = state_stride;
+  a.sv_gates = sv_gates; a.sv_cprev = sv_cprev; a.sv_hprev = sv_hprev; a.sv_tanhc = sv_tanhc;
   a.XS = x_stride(net->ob_dim); a.HP = net->hidden + 2;
   size_t lds = (size_t)(16 * a.XS + 16 * HS + 2 * 16 * a.HP) * sizeof(float);
   int tiles = (n + 15) / 16;
@@ -403,6 +414,163 @@ extern "C" int ppo_lstm_step(const ppo_lstm_net* net, const float* obs, int n, i
   else if (net->hidden == 64) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IJFO>), g, b, lds, st, a);
   else if (ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IFOU>), g, b, lds, st, a);
   else hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IJFO>), g, b, lds, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int ppo_lstm_step(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
+                             int state_stride, const float* noise, const float* given_action, float* action_out,
+                             float* neglogp_out, float* value_out, float* mean_out, void* stream) {
+  return lstm_launch(net, obs, n, obs_stride, mask, c, h, state_stride, noise, given_action, action_out, neglogp_out, value_out, mean_out,
+                     nullptr, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int ppo_lstm_step_save(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
+                                  int state_stride, float* save_gates, float* save_cprev, float* save_hprev, float* save_tanhc,
+                                  void* stream) {
+  if (!save_gates || !save_cprev || !save_hprev || !save_tanhc) FAIL(-1, "bad arguments");
+  return lstm_launch(net, obs, n, obs_stride, mask, c, h, state_stride, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, save_gates,
+                     save_cprev, save_hprev, save_tanhc, stream);
+}
+
+// ---- loss heads on stored latents: one thread per row (rows x hidden x (ac_dim + 1) MACs: small next to the recurrence)
+__global__ void __launch_bounds__(128) ppo_lstm_head_grad_kernel(ppo_lstm_net N, const float* latent, int rows, const float* actions,
+                                                                 const float* adv, const float* returns, const float* oldnlp,
+                                                                 const float* weight, float inv_count, float cliprange, float vf_coef,
+                                                                 float* dlatent, float* dmean_o, float* dvalue_o, float* dlogstd_rows,
+                                                                 double* stats) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Hh = N.hidden, A = N.ac_dim;
+  double s_pg = 0, s_vf = 0, s_kl = 0, s_cf = 0, s_n = 0;
+  if (r < rows) {
+    const float* L = latent + (size_t)r * Hh;
+    float mean[MAXA], value = N.vf_b[0];
+    for (int q = 0; q < A; q++) mean[q] = N.head_b[q];
+    for (int k = 0; k < Hh; k++) {
+      const float lk = L[k];
+      value += lk * N.vf_w[k];
+      for (int q = 0; q < A; q++) mean[q] += lk * N.head_w[k * A + q];
+    }
+    float ss = 0, sum_logstd = 0, zq[MAXA], isd[MAXA];
+    for (int q = 0; q < A; q++) {
+      const float ls = N.logstd[q];
+      isd[q] = expf(-ls);
+      zq[q] = (actions[(size_t)r * A + q] - mean[q]) * isd[q];
+      ss += zq[q] * zq[q]; sum_logstd += ls;
+    }
+    const float nlp = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
+    const float old = oldnlp[r], ad = adv[r], w = weight[r], R = returns[r];
+    float ratio = expf(old - nlp);
+    const bool isnan_ = ratio != ratio;
+    if (isnan_) ratio = 2.0f;                                                       // model.py:96
+    const float rc = fminf(fmaxf(ratio, 1.0f - cliprange), 1.0f + cliprange);
+    const float l1 = -ad * ratio, l2 = -ad * rc;
+    const bool in_clip = ratio >= 1.0f - cliprange && ratio <= 1.0f + cliprange;
+    float dratio = l1 >= l2 ? -ad : (in_clip ? -ad : 0.0f);                         // tf.maximum: ties go to the first argument
+    dratio = isnan_ ? 0.0f : dratio * w * inv_count;
+    const float dnlp = -dratio * ratio;
+    const float dv = vf_coef * (value - R) * inv_count;
+    s_pg = (double)(w * fmaxf(l1, l2)); s_vf = 0.5 * (double)(value - R) * (double)(value - R);
+    s_kl = (double)(nlp - old); s_cf = fabsf(ratio - 1.0f) > cliprange ? 1.0 : 0.0; s_n = 1.0;
+    float dm[MAXA];
+    for (int q = 0; q < A; q++) {
+      dm[q] = dnlp * (-(zq[q] * isd[q]));
+      dmean_o[(size_t)r * A + q] = dm[q];
+      dlogstd_rows[(size_t)r * A + q] = dnlp * (1.0f - zq[q] * zq[q]);
+    }
+    dvalue_o[r] = dv;
+    float* dl = dlatent + (size_t)r * Hh;
+    for (int k = 0; k < Hh; k++) {
+      float acc = dv * N.vf_w[k];
+      for (int q = 0; q < A; q++) acc += dm[q] * N.head_w[k * A + q];
+      dl[k] = acc;
+    }
+  }
+  __shared__ double red[5][128];
+  red[0][threadIdx.x] = s_pg; red[1][threadIdx.x] = s_vf; red[2][threadIdx.x] = s_kl; red[3][threadIdx.x] = s_cf; red[4][threadIdx.x] = s_n;
+  __syncthreads();
+  for (int o = 64; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) for (int q = 0; q < 5; q++) red[q][threadIdx.x] += red[q][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(stats + 0, red[0][0]); atomicAdd(stats + 1, red[1][0]); atomicAdd(stats + 3, red[2][0]); atomicAdd(stats + 4, red[3][0]);
+    atomicAdd(stats + 6, red[4][0]);
+  }
+}
+extern "C" int ppo_lstm_head_grad(const ppo_lstm_net* net, const float* latent, int rows, const float* actions, const float* adv,
+                                  const float* returns, const float* old_neglogp, const float* is_weight, double inv_count,
+                                  float cliprange, float vf_coef, float* dlatent, float* dmean, float* dvalue, float* dlogstd_rows,
+                                  double* stats, void* stream) {
+  if (!net || !latent || !actions || !adv || !returns || !old_neglogp || !is_weight || !dlatent || !dmean || !dvalue || !dlogstd_rows ||
+      !stats || rows <= 0)
+    FAIL(-1, "bad arguments");
+  if (!net->head_w || !net->head_b || !net->logstd || !net->vf_w || !net->vf_b || net->ac_dim < 1 || net->ac_dim > MAXA)
+    FAIL(-2, "both heads are needed");
+  hipLaunchKernelGGL(ppo_lstm_head_grad_kernel, dim3((rows + 127) / 128), dim3(128), 0, (hipStream_t)stream, *net, latent, rows, actions,
+                     adv, returns, old_neglogp, is_weight, (float)inv_count, cliprange, vf_coef, dlatent, dmean, dvalue, dlogstd_rows, stats);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- one BPTT step (gate order i,f,o,u).  One wave per 16-row tile; LDS: dz [16][4*NH + 2]
+template <int NH>
+__global__ void __launch_bounds__(64) ppo_lstm_bwd_step_kernel(const float* wh, int n, const float* dlat, const float* mask,
+                                                               const float* gates, const float* cprev, const float* tanhc, float* dh_c,
+                                                               float* dc_c, float* dz_out) {
+  constexpr int ZS = 4 * NH + 2;
+  float* dzb = smem_f;
+  const int lane = threadIdx.x, r0 = blockIdx.x * 16;
+  // elementwise part: thread e -> (row, unit)
+  for (int e = lane; e < 16 * NH; e += WAVE) {
+    const int r = e / NH, j = e - r * NH, row = r0 + r;
+    float dzi = 0, dzf = 0, dzo = 0, dzu = 0;
+    if (row < n) {
+      const size_t o = (size_t)row * NH + j;
+      const float* g = gates + (size_t)row * 4 * NH;
+      const float ig = g[j], fg = g[NH + j], og = g[2 * NH + j], ug = g[3 * NH + j], tc = tanhc[o], cp = cprev[o];
+      const float dht = dlat[o] + dh_c[o];
+      const float dct = dc_c[o] + dht * og * (1.0f - tc * tc);
+      dzi = dct * ug * ig * (1.0f - ig); dzf = dct * cp * fg * (1.0f - fg); dzo = dht * tc * og * (1.0f - og); dzu = dct * ig * (1.0f - ug * ug);
+      const float keep = mask ? 1.0f - mask[row] : 1.0f;
+      dc_c[o] = dct * fg * keep;
+      float* z = dz_out + (size_t)row * 4 * NH;
+      z[j] = dzi; z[NH + j] = dzf; z[2 * NH + j] = dzo; z[3 * NH + j] = dzu;
+    }
+    dzb[r * ZS + j] = dzi; dzb[r * ZS + NH + j] = dzf; dzb[r * ZS + 2 * NH + j] = dzo; dzb[r * ZS + 3 * NH + j] = dzu;
+  }
+  wave_sync();
+  // dh_prev = dz * wh^T : [16 x 4NH] x [4NH x NH]
+  const int i = lane & 15, kq = lane >> 4;
+  constexpr int NT = NH / 16;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
+  for (int k0 = 0; k0 < 4 * NH; k0 += 4) {
+    const int k = k0 + kq;
+    const float av = dzb[i * ZS + k];
+#pragma unroll
+    for (int ct = 0; ct < NT; ct++) acc[ct] = MFMA(av, wh[(size_t)(ct * 16 + i) * 4 * NH + k], acc[ct]);   // B[k][col] = wh[col][k]
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 4 * kq + r;
+      if (row < n) dh_c[(size_t)row * NH + ct * 16 + i] = acc[ct][r] * (mask ? 1.0f - mask[row] : 1.0f);
+    }
+}
+extern "C" int ppo_lstm_bwd_step(const ppo_lstm_net* net, int n, const float* dlatent_t, const float* mask_t, const float* gates_t,
+                                 const float* cprev_t, const float* tanhc_t, float* dh_carry, float* dc_carry, float* dz_out, void* stream) {
+  if (!net || !net->wh || !dlatent_t || !gates_t || !cprev_t || !tanhc_t || !dh_carry || !dc_carry || !dz_out || n <= 0) FAIL(-1, "bad arguments");
+  if (net->gate_order != PPO_LSTM_GATES_IFOU) FAIL(-2, "backward is built for the (i,f,o,u) gate order only");
+  if (net->hidden != 64 && net->hidden != 128) FAIL(-3, "hidden %d: only 64 and 128 are built", net->hidden);
+  const int tiles = (n + 15) / 16;
+  const size_t lds = (size_t)16 * (4 * net->hidden + 2) * sizeof(float);
+  if (net->hidden == 64)
+    hipLaunchKernelGGL(ppo_lstm_bwd_step_kernel<64>, dim3(tiles), dim3(64), lds, (hipStream_t)stream, net->wh, n, dlatent_t, mask_t, gates_t,
+                       cprev_t, tanhc_t, dh_carry, dc_carry, dz_out);
+  else
+    hipLaunchKernelGGL(ppo_lstm_bwd_step_kernel<128>, dim3(tiles), dim3(64), lds, (hipStream_t)stream, net->wh, n, dlatent_t, mask_t, gates_t,
+                       cprev_t, tanhc_t, dh_carry, dc_carry, dz_out);
   HIPCHK(hipGetLastError());
   return 0;
 }

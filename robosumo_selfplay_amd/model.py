@@ -94,6 +94,7 @@ class PPOModel(object):
     # is captured once per (batch arrays, minibatch size, cliprange) into a HIP graph and replayed with a fresh index
     # vector; only the Adam step stays outside (its step count is a host scalar).  Single-GPU, asynchronous path only.
     use_graph = os.environ.get("SUMO_PPO_GRAPH", "1") != "0"
+    equal_counts = True   # multi-GPU: minibatches have the same size on every rank (learn() clears it for opponent-data reuse)
 
     def _launch_loss_grad(self, obs, returns, actions, values, neglogpacs, weights, idx, n, cliprange, adv, log_ratio, st):
         L = ppo_capi.lib()
@@ -175,10 +176,12 @@ class PPOModel(object):
         sdist.allreduce_moments(self.moments, self.comm)
         adv = t.empty(n, dtype=t.float32, device=self.device)
         ppo_capi.chk(L.ppo_adv_normalize(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), adv.data_ptr(), st))
-        if self.comm is not None:
-            count = float(self.moments[2].item())
-        else:
+        if self.comm is None:
             count = float(n)
+        elif self.equal_counts:       # every rank contributes the same number of rows: no host read-back of the all-reduced count
+            count = float(n) * self._t.distributed.get_world_size(self.comm)
+        else:
+            count = float(self.moments[2].item())
         self.stats.zero_()
         log_ratio = t.empty(n, dtype=t.float32, device=self.device)
         ppo_capi.chk(L.ppo_grad(self.params.data_ptr(), obs.data_ptr(), obs.stride(0), D, A, actions.data_ptr(), adv.data_ptr(),

@@ -72,6 +72,11 @@ def build_policy(env, policy_network="mlp", value_network=None, normalize_observ
     defaults always pass 'copy' (defaults.py:22)."""
     if normalize_observations or estimate_q:
         raise NotImplementedError("normalize_observations / estimate_q are off in the reference defaults")
+    if policy_network == "lstm":                      # models.py:131-183; recurrent nets share the latent (policies.py:176-181)
+        from .lstm_model import LstmSpec
+        if value_network not in (None, "shared"):
+            raise NotImplementedError("recurrent architectures are not supported with value_network=copy (reference policies.py:179)")
+        return LstmSpec(env.observation_space[0].shape[0], env.action_space[0].shape[0], nlstm=policy_kwargs.get("nlstm", 128))
     return PolicySpec(env.observation_space[0].shape[0], env.action_space[0].shape[0], policy_network,
                       value_network if value_network is not None else "shared", **policy_kwargs)
 

@@ -168,6 +168,9 @@ class Runner(AbstractEnvRunner):
         opp_obs, opp_act, epinfos = [], [], []
         info_steps, env_rew_steps = [], []
         use_info = None
+        # recurrent nets: the state at the START of the rollout is what back-propagation through time begins from (the
+        # reference returns the list slot after the loop, i.e. the final state -- its recurrent training path is dead code)
+        mb_states0 = None if self.states[0] is None else np.array(self.states[0], copy=True)
         for _ in range(T):
             acts = []
             for agt in range(A_):
@@ -228,4 +231,4 @@ class Runner(AbstractEnvRunner):
         mb_onlp_np = np.asarray(mb_onlp)
         return (*map(sf01, (mb_obs, n(returns), mb_dones_np, mb_actions, np.asarray(mb_values, np.float32),
                             np.asarray(mb_nlp, np.float32), n(rew), mb_onlp_np, opp_obs, opp_act)),
-                self.states[0], epinfos, *map(lambda x: sf0(n(x)), (opr, oer, ratio)))
+                mb_states0, epinfos, *map(lambda x: sf0(n(x)), (opr, oer, ratio)))
