@@ -59,8 +59,8 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
     recurrent = network == "lstm"
     if recurrent:
         from .lstm_model import LstmPPOModel
-        if use_opponent_data is not None or comm is not None:
-            raise NotImplementedError("recurrent policies: no opponent-data reuse, single GPU")
+        if use_opponent_data is not None:
+            raise NotImplementedError("recurrent policies: no opponent-data reuse")
         assert nenvs % nminibatches == 0, "recurrent minibatches are whole env sequences: nenvs %% nminibatches must be 0"
     model_fn = model_fn or (LstmPPOModel if recurrent else PPOModel)
     dev = getattr(env, "device", torch.device("cuda", 0))

@@ -15,7 +15,7 @@ import os
 
 import numpy as np
 
-from . import policies, ppo_capi
+from . import dist as sdist, policies, ppo_capi
 
 
 class LstmSpec(object):
@@ -34,8 +34,7 @@ class LstmPPOModel(object):
         import torch
         if not torch.cuda.is_available():
             raise ppo_capi.PpoHipError("LstmPPOModel needs a HIP device (no CPU fallback in the product path)")
-        if comm is not None:
-            raise NotImplementedError("recurrent training is single-GPU so far")
+        self.comm = comm if trainable else None      # torch.distributed group: every rank trains on its own env sequences
         self._t = torch
         self.spec, self.scope, self.sess = policy, model_scope, None
         self.device = torch.device("cuda", int(device))
@@ -56,7 +55,7 @@ class LstmPPOModel(object):
             self.m = torch.zeros(self.P, dtype=torch.float32, device=self.device)
             self.v = torch.zeros(self.P, dtype=torch.float32, device=self.device)
             self.t = 0
-            self.grads = torch.zeros(self.P, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(self.P + ppo_capi.NSTATS, dtype=torch.float32, device=self.device)   # [flat grad | loss sums]
             self.gviews = self._split(self.grads)
             self.stats = torch.zeros(ppo_capi.NSTATS, dtype=torch.float64, device=self.device)
             self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
@@ -144,7 +143,7 @@ class LstmPPOModel(object):
         return self._run(observation, S, M, given_action=given_action)[3]
 
     # ---- training ---------------------------------------------------------------------------------------------------
-    def loss_and_grads(self, cliprange, obs, returns, masks, actions, advs, neglogpacs, IS_weight, states, nsteps):
+    def loss_and_grads(self, cliprange, obs, returns, masks, actions, advs, neglogpacs, IS_weight, states, nsteps, world=1):
         """Forward over ``nsteps`` + BPTT for a minibatch of whole env sequences.  Flat inputs are env-major
         ([nenv_mb * nsteps, ...], baselines' ``sf01`` order); ``states`` [nenv_mb, 2H] is the state at the start of the
         sequences.  Leaves d(mean loss)/d(theta) in ``self.grads``, the un-normalised loss sums in ``self.stats``."""
@@ -174,7 +173,7 @@ class LstmPPOModel(object):
         dls = t.empty((rows, A), dtype=f32, device=dev)
         self.stats.zero_()
         ppo_capi.chk(L.ppo_lstm_head_grad(net, lat.data_ptr(), rows, Ac.data_ptr(), Ad.data_ptr(), R.data_ptr(), Old.data_ptr(), W.data_ptr(),
-                                          1.0 / rows, float(cliprange), self.vf_coef, dlat.data_ptr(), dmean.data_ptr(), dvalue.data_ptr(),
+                                          1.0 / (rows * world), float(cliprange), self.vf_coef, dlat.data_ptr(), dmean.data_ptr(), dvalue.data_ptr(),
                                           dls.data_ptr(), self.stats.data_ptr(), st))
         dh = t.zeros((n, H), dtype=f32, device=dev)
         dc = t.zeros((n, H), dtype=f32, device=dev)
@@ -190,7 +189,7 @@ class LstmPPOModel(object):
         t.sum(Z2, dim=0, out=g[2])
         t.matmul(L2.t(), dmean, out=g[3])
         t.sum(dmean, dim=0, out=g[4])
-        g[5].copy_((dls.sum(dim=0) - self.ent_coef).view(1, A))
+        g[5].copy_((dls.sum(dim=0) - self.ent_coef / world).view(1, A))     # the entropy term once in the global sum
         t.matmul(L2.t(), dvalue.view(rows, 1), out=g[6])
         g[7].copy_(dvalue.sum().view(1))
         return state
@@ -208,9 +207,15 @@ class LstmPPOModel(object):
         nrow = ret.numel()
         st = t.cuda.current_stream(self.device).cuda_stream
         adv = t.empty(nrow, dtype=t.float32, device=self.device)                        # model.py:180-185
+        world = 1 if self.comm is None else t.distributed.get_world_size(self.comm)
         ppo_capi.chk(L.ppo_adv_moments(ret.data_ptr(), val.data_ptr(), None, nrow, self.moments.data_ptr(), st))
+        sdist.allreduce_moments(self.moments, self.comm)                                # global advantage normalisation
         ppo_capi.chk(L.ppo_adv_normalize(ret.data_ptr(), val.data_ptr(), None, nrow, self.moments.data_ptr(), adv.data_ptr(), st))
-        self.loss_and_grads(cliprange, obs, ret, masks, actions, adv, neglogpacs, IS_weight, states, T)
+        self.loss_and_grads(cliprange, obs, ret, masks, actions, adv, neglogpacs, IS_weight, states, T, world=world)
+        if self.comm is not None:            # ONE fused collective per optimiser step: [flat grad | loss sums] (equal shards per rank)
+            self.grads[self.P:] = self.stats.to(t.float32)
+            sdist.allreduce_fused(self.grads, self.comm)
+            self.stats.copy_(self.grads[self.P:].to(t.float64))
         A = self.spec.ac_dim
         entropy = float((self.views[5].double() + 0.5 * np.log(2.0 * np.pi * np.e)).sum().item())
         self.t += 1

@@ -76,3 +76,73 @@ def test_two_shards_match_single_process():
     assert np.allclose(res[0][0], ref_p, rtol=0, atol=2e-5), np.abs(res[0][0] - ref_p).max()
     assert np.allclose(res[0][1], ref_st, rtol=1e-3, atol=1e-5)      # loss statistics are global means
     assert np.allclose(res[1][1], ref_st, rtol=1e-3, atol=1e-5)
+
+
+# ---- the same for the recurrent model: each rank back-propagates through its own env sequences -----------------------
+LT, LN, LD, LA, LH = 6, 16, 17, 3, 64
+
+
+def _lstm_batch():
+    rng = np.random.RandomState(11)
+    obs = rng.normal(0, 1, (LN, LT, LD)).astype(np.float32)
+    masks = rng.rand(LN, LT) < 0.2
+    act = rng.normal(0, 0.7, (LN, LT, LA)).astype(np.float32)
+    ret = rng.normal(0, 1, (LN, LT)).astype(np.float32)
+    val = rng.normal(0, 1, (LN, LT)).astype(np.float32)
+    old = rng.normal(3.5, 0.3, (LN, LT)).astype(np.float32)
+    S0 = rng.normal(0, 0.5, (LN, 2 * LH)).astype(np.float32)
+    return obs, masks, act, ret, val, old, S0
+
+
+def _lstm_train(comm, lo, hi, steps=3):
+    from robosumo_selfplay_amd import dist as sdist, lstm_model
+    np.random.seed(3)
+    m = lstm_model.LstmPPOModel(policy=lstm_model.LstmSpec(LD, LA, LH), ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, comm=comm,
+                                nbatch_act=hi - lo, nsteps=LT)
+    sdist.broadcast_params(m.params, comm)
+    obs, masks, act, ret, val, old, S0 = (x[lo:hi] for x in _lstm_batch())
+    n = hi - lo
+    flat = lambda x: np.ascontiguousarray(x).reshape(n * LT, *x.shape[2:])
+    out = None
+    for _ in range(steps):
+        out = m.train(1e-3, 0.2, flat(obs), flat(ret), flat(masks), flat(act), flat(val), flat(old), None, np.ones(n * LT, np.float32),
+                      states=S0)
+    sdist.assert_synced(m.params, comm)
+    return m.params.cpu().numpy(), np.array([float(x) for x in out[:5]])
+
+
+def _lstm_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = LN // world
+    p, st = _lstm_train(dist.group.WORLD, rank * per, (rank + 1) * per)
+    q.put((rank, p, st))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_two_shards_match_single_process_recurrent():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lstm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, p, st = q.get(timeout=300)
+        res[r] = (p, st)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref_p, ref_st = _lstm_train(None, 0, LN)
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.allclose(res[0][0], ref_p, rtol=0, atol=3e-5), np.abs(res[0][0] - ref_p).max()
+    assert np.allclose(res[0][1], ref_st, rtol=2e-3, atol=1e-5) and np.allclose(res[1][1], ref_st, rtol=2e-3, atol=1e-5)
