@@ -22,6 +22,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "../../include/sumo_hip.h"
 #include "../../include/sumo_model.h"
 
@@ -93,6 +95,8 @@ struct StepArgs {
   double* ep_dr;
   int* ep_l;
   const uint8_t* mask;  // reset only
+  const int* perm;      // step: workgroup b advances env perm[b] (NULL = identity); see sumo_step
+  int* cost;            // step: per-env work estimate written for the next launch's schedule
   unsigned long long* stats;
   int obs_stride, act_stride;
   int N;
@@ -1808,8 +1812,9 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
-  const int e = blockIdx.x, lane = c.lane;
-  if (e >= a.N) return;
+  const int lane = c.lane;
+  if ((int)blockIdx.x >= a.N) return;
+  const int e = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;
   load_state(c, a, e);
   if (lane < mdl.nu) {
     const float* act0 = a.actions + (size_t)e * 2 * a.act_stride;
@@ -1887,6 +1892,9 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   store_state(c, a, e);
   if (lane == 0) { cnt[0] = num_steps; cnt[1] = reset_count; st[mdl.nq + 2 * mdl.nv] = ep_ret; st[mdl.nq + 2 * mdl.nv + 1] = ep_dense; }
   PROF(19);
+  // work estimate for the next launch's longest-first schedule (sumo_step): Newton iterations dominate the variation
+  // (a contention-independent proxy; sorting by the measured cycle count of the previous step schedules no better)
+  if (lane == 0 && a.cost) a.cost[e] = 1600 + 12 * c.st_newton + 2 * c.st_ncon + (dn ? 150 : 0);
   flush_stats(c, a.stats);
 }
 
@@ -1963,6 +1971,11 @@ struct sumo_engine {
   int* d_counters = nullptr;
   uint64_t* d_seeds = nullptr;
   unsigned long long* d_stats = nullptr;
+  // longest-first scheduling of the env steps (see sumo_step)
+  int *d_cost = nullptr, *d_cost_sorted = nullptr, *d_iota = nullptr, *d_perm = nullptr;
+  void* d_sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  bool sched = true, perm_valid = false;
   int state_stride, obs_stride, act_stride;
 };
 
@@ -2350,6 +2363,20 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
   HIPCHK(hipMemcpy(E->d_seeds, seeds.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIPCHK(hipMalloc((void**)&E->d_stats, 32 * sizeof(unsigned long long)));
   HIPCHK(hipMemset(E->d_stats, 0, 32 * sizeof(unsigned long long)));
+  {
+    const char* sc = getenv("SUMO_SCHED");
+    E->sched = !(sc && atoi(sc) == 0);
+    HIPCHK(hipMalloc((void**)&E->d_cost, N * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&E->d_cost_sorted, N * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&E->d_iota, N * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&E->d_perm, N * sizeof(int)));
+    std::vector<int> iota(N);
+    for (size_t i = 0; i < N; i++) iota[i] = (int)i;
+    HIPCHK(hipMemcpy(E->d_iota, iota.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, E->sort_tmp_bytes, E->d_cost, E->d_cost_sorted, E->d_iota, E->d_perm, N, 0, 16,
+                                          (hipStream_t)0));
+    HIPCHK(hipMalloc(&E->d_sort_tmp, E->sort_tmp_bytes ? E->sort_tmp_bytes : 16));
+  }
   // qpos = qpos0 for every env until the first reset / set_state
   {
     std::vector<double> st(N * E->state_stride, 0.0);
@@ -2375,6 +2402,7 @@ extern "C" int sumo_destroy(sumo_handle_t E) {
   (void)hipSetDevice(E->device);
   (void)hipFree(E->d_params); (void)hipFree(E->d_lanes); (void)hipFree(E->d_pair_rec); (void)hipFree(E->d_pair_bound); (void)hipFree(E->d_blob); (void)hipFree(E->d_ai); (void)hipFree(E->d_af); (void)hipFree(E->d_pic); (void)hipFree(E->d_state);
   (void)hipFree(E->d_counters); (void)hipFree(E->d_seeds); (void)hipFree(E->d_stats);
+  (void)hipFree(E->d_cost); (void)hipFree(E->d_cost_sorted); (void)hipFree(E->d_iota); (void)hipFree(E->d_perm); (void)hipFree(E->d_sort_tmp);
   delete E;
   return 0;
 }
@@ -2438,8 +2466,17 @@ extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_d
   StepArgs a = base_args(E);
   a.actions = actions_dev; a.obs = obs_dev; a.info = info_dev; a.done = done_dev; a.ep_r = ep_r_dev; a.ep_dr = ep_dr_dev;
   a.ep_l = ep_l_dev;
+  // Env steps differ in cost (Newton iterations, contacts) by up to ~1.6x and a launch is only N / (6 * 256) rounds deep, so
+  // the slowest workgroups of the last round set the launch time.  Workgroups are dispatched in index order: hand the
+  // envs out longest-first, using the work each env reported in its previous step (results do not depend on the order).
+  if (E->sched) { a.cost = E->d_cost; a.perm = E->perm_valid ? E->d_perm : nullptr; }
   SUMO_DISPATCH(sumo_step_kernel, E, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
+  if (E->sched) {
+    HIPCHK(rocprim::radix_sort_pairs_desc(E->d_sort_tmp, E->sort_tmp_bytes, E->d_cost, E->d_cost_sorted, E->d_iota, E->d_perm,
+                                          (size_t)E->N, 0, 16, (hipStream_t)stream));
+    E->perm_valid = true;
+  }
   return 0;
 }
 
