@@ -51,6 +51,9 @@ def main(argv):
     env = make_vec_env(args.env, per, args.seed + start, device=local_rank)  # run.py:144: env i gets seed + i
     kw = defaults.get_default_params(args.env, args.algo)
     kw.update(extra)
+    if args.network == "lstm":       # the RoboSumo defaults describe the MLP (defaults.py:8-26); recurrent nets share the latent
+        for k in ("value_network", "num_hidden", "num_layers", "activation"):
+            kw.pop(k, None)
     if rank == 0:
         with open(os.path.join(log_path, "config.pkl"), "wb") as f:        # run.py:176-177
             pickle.dump(dict(vars(args), **kw), f)
