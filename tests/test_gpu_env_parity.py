@@ -216,3 +216,25 @@ def test_vecenv_host_api_matches_reference_contract():
     env.close()
     with pytest.raises(AssertionError):
         env.reset()
+
+
+def test_longest_first_schedule_does_not_change_results(monkeypatch):
+    """sumo_step hands the envs to workgroups longest-first (per-env work estimate of the previous step); the order must
+    not leak into the results: same seeds with the schedule on and off give identical bits for every env."""
+    N, K = 256, 12
+    rng = np.random.default_rng(11)
+    acts = [torch.from_numpy(rng.standard_normal((N, 2, 8)).astype(np.float32)).cuda() for _ in range(K)]
+    outs = []
+    for sched in ("1", "0"):
+        monkeypatch.setenv("SUMO_SCHED", sched)
+        env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=N, seed=21)
+        env.reset_device()
+        rec = []
+        for a in acts:
+            obs, info, done, ep_r, _, ep_l = env.step_device(a)
+            rec.append((obs.clone(), info.clone(), done.clone(), ep_l.clone()))
+        torch.cuda.synchronize()
+        outs.append(rec)
+        env.close()
+    for (o1, i1, d1, l1), (o0, i0, d0, l0) in zip(*outs):
+        assert torch.equal(o1, o0) and torch.equal(i1, i0) and torch.equal(d1, d0) and torch.equal(l1, l0)
