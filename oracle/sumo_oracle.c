@@ -522,6 +522,18 @@ static void collision(const so_sim* s, env_t* d) {
       c->g1 = g1; c->g2 = g2;
     }
   }
+  /* The HIP engine keeps contact Jacobians in a pool of maxcon + maxcon/3 "halves" (one per moving body of a contact):
+   * the first contact, in pair order, that does not fit and all later ones are dropped and counted.  Mirrored here so the
+   * two stay comparable when the pool overflows (only with > 16 simultaneous contacts between moving bodies). */
+  {
+    const int* gbody = SUMO_I(m, geom_bodyid);
+    int cap = s->maxcon + s->maxcon / 3, used = 0;
+    for (int i = 0; i < d->ncon; i++) {
+      int nh = (gbody[d->con[i].g1] != 0 && gbody[d->con[i].g2] != 0) ? 2 : 1;
+      if (used + nh > cap) { d->ncon_dropped += d->ncon - i; d->ncon = i; break; }
+      used += nh;
+    }
+  }
 }
 
 /* ------------------------------------------------------------------------------------------------

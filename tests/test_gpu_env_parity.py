@@ -238,3 +238,42 @@ def test_longest_first_schedule_does_not_change_results(monkeypatch):
         env.close()
     for (o1, i1, d1, l1), (o0, i0, d0, l0) in zip(*outs):
         assert torch.equal(o1, o0) and torch.equal(i1, i0) and torch.equal(d1, d0) and torch.equal(l1, l0)
+
+
+@pytest.mark.parametrize("env_id,tol", [("RoboSumo-Ant-vs-Ant-v0", 1e-8), ("RoboSumo-Ant-vs-Spider-v0", 1e-6)])
+def test_step_parity_when_agents_wrestle(env_id, tol):
+    """Agents placed leg-to-leg so that most forward-dynamics calls carry contacts between two MOVING bodies: this is the
+    general (non tree-sparse) factorisation path and the two-sided contact Jacobians, which free play rarely reaches."""
+    p = Pair(env_id, 48)
+    p.reset()
+    q, v, w, c = p.ora.get_state()
+    m = p.m
+    a0, a1 = int(m.agent_qposadr[0]), int(m.agent_qposadr[1])
+    rng = np.random.default_rng(5)
+    for e in range(p.N):
+        ang = rng.uniform(0, 2 * np.pi)
+        d = rng.uniform(0.55, 0.95)                       # torso distance: legs overlap (torso radius 0.25, legs reach ~0.9)
+        ctr = rng.uniform(-0.3, 0.3, 2)
+        q[e, a0:a0 + 2] = ctr + 0.5 * d * np.array([np.cos(ang), np.sin(ang)])
+        q[e, a1:a1 + 2] = ctr - 0.5 * d * np.array([np.cos(ang), np.sin(ang)])
+    v[:] *= 0.5
+    p.ora.set_state(q, v, w, c)
+    p.eng.set_state(q, v, w, c)
+    two_body = 0
+    gb = m.tables["geom_bodyid"]
+    for t in range(12):
+        a = (rng.standard_normal((p.N, 2, p.eng.act_stride)) * 0.7).astype(np.float32)
+        (gobs, ginfo, gdone, gr, gdr, gl), (oobs, oinfo, odone, orr, odr, ol) = p.step(a)
+        assert np.array_equal(gdone, odone) and np.array_equal(gl, ol)
+        assert np.abs(gobs - oobs).max() < 2e-5
+        gs, os_ = p.eng.get_state(), p.ora.get_state()
+        assert relerr(gs[0], os_[0]) < tol and relerr(gs[1], os_[1]) < 1e2 * tol, (t, relerr(gs[0], os_[0]), relerr(gs[1], os_[1]))
+        for e in range(0, p.N, 8):
+            p.ora.forward(e)
+            con = p.ora.array("contacts", e).reshape(-1, 9)
+            two_body += int(any(gb[int(cc[7])] != 0 and gb[int(cc[8])] != 0 for cc in con))
+        p.eng.set_state(*os_)
+    gst, ost = p.eng.stats(), p.ora.stats()
+    # (deep interpenetration can exceed the Jacobian pool: both sides drop the same contacts, in pair order)
+    assert gst["dropped"] == ost["dropped"] and gst["max_ncon"] == ost["max_ncon"]
+    assert two_body >= 12, two_body          # the scenario really exercises contacts between the agents
