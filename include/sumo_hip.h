@@ -56,8 +56,9 @@ int sumo_debug_forward(sumo_handle_t h, const double* ctrl, double* qacc, int32_
 /* device-side statistics accumulated since creation: forward calls, newton iterations, contacts, efc rows,
  * max ncon, max nefc, max newton iterations, dropped contacts (HOST float64 [8]). */
 int sumo_stats(sumo_handle_t h, double* out8);
-/* per-phase shader-cycle totals; all zero unless the library was built with -DSUMO_PROFILE (HOST float64 [20]). */
-int sumo_profile(sumo_handle_t h, double* out20);
+/* per-phase shader-cycle totals (20 phases + 4 ad-hoc probe slots); all zero unless the library was built with
+ * -DSUMO_PROFILE (HOST float64 [24]). */
+int sumo_profile(sumo_handle_t h, double* out24);
 
 #ifdef __cplusplus
 }

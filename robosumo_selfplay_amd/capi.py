@@ -128,7 +128,7 @@ class Engine:
         return qacc, counts
 
     def profile(self):
-        o = np.zeros(20)
+        o = np.zeros(24)
         _chk(lib().sumo_profile(self.h, _np(o)))
         return o
 

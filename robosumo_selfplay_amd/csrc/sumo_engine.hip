@@ -52,6 +52,7 @@ struct Aux {  // derived integer tables (built on the host in build_aux)
   int o_stat_d, n_stat_d, o_stat_i, n_stat_i;  // tables copied into LDS at kernel start (see build_aux)
   int o_wpa;                                   // double table: world geom positions [3*nworld] | axes [3*nworld]
   int nc, nworld;  // collision centres: bodies 0..nbody-1, then one per world geom
+  int maxchild;               // largest number of children of any body
   int nwp, wrounds, arounds;  // pairs with a static world geom (listed first), rounds of 64 for them / for the rest
 };
 
@@ -389,7 +390,7 @@ struct Ctx {
   int ncon, nlim, nefc, ndropped, use_prev, htree;  // htree: every contact has one moving body -> H is tree-sparse like M
 #ifdef SUMO_PROFILE
   long long tprev;
-  unsigned long long prof[20];
+  unsigned long long prof[24];   // 20 phases + 4 ad-hoc probe slots (PROBE(k))
 #endif
   // statistics accumulated over the launch
   int st_forward, st_newton, st_ncon, st_nefc, st_maxcon, st_maxefc, st_maxnewton, st_dropped;
@@ -411,6 +412,7 @@ __device__ __forceinline__ const T* launder_ptr(const T* p) { asm volatile("" : 
 #else
 #define PROF(k) do { } while (0)
 #endif
+#define PROBE(k) PROF(20 + (k))   /* development: split a phase; the time up to the probe goes to slot 20+k */
 
 // ---- position / velocity stage --------------------------------------------------------------------------
 #define BYTE_OF(word64, p) ((int)(((word64) >> (8 * (p))) & 0xFFull))
@@ -461,20 +463,41 @@ __device__ __forceinline__ void kin_own_body(C& c) {  // lane == body id
   S(gaxis)[3 * b] = R[2]; S(gaxis)[3 * b + 1] = R[5]; S(gaxis)[3 * b + 2] = R[8];
 }
 
-// gather children into parents, level by level, for an array of `w` doubles per body (lane == body id)
-template <class C>
-__device__ __forceinline__ void gather_up(C& c, double* arr, int w) {
+// gather children into parents, level by level, for an array of W doubles per body (lane == body id).  The sums are
+// accumulated in registers with the loads of all (up to 8) children issued together: one LDS round trip per level instead
+// of a read-modify-write chain per child.
+template <int W, int NCH, class C>
+__device__ __forceinline__ void gather_up_n(C& c, double* arr) {
   KCONSTS();
   const int b = c.lane;
   for (int lvl = c.P->aux.ndepth - 2; lvl >= 1; lvl--) {
-    if (K.b_level == lvl) {
-      for (int ci = 0; ci < K.b_nchild; ci++) {
-        int ch = BYTE_OF(K.b_child, ci);
-        for (int k = 0; k < w; k++) arr[w * b + k] += arr[w * ch + k];
+    if (K.b_level == lvl && K.b_nchild > 0) {
+      double acc[W], ch[NCH][W];
+#pragma unroll
+      for (int k = 0; k < W; k++) acc[k] = arr[W * b + k];
+#pragma unroll
+      for (int ci = 0; ci < NCH; ci++) {
+        const int cb = BYTE_OF(K.b_child, ci < K.b_nchild ? ci : 0);
+#pragma unroll
+        for (int k = 0; k < W; k++) ch[ci][k] = arr[W * cb + k];
       }
+#pragma unroll
+      for (int ci = 0; ci < NCH; ci++)
+        if (ci < K.b_nchild) {
+#pragma unroll
+          for (int k = 0; k < W; k++) acc[k] += ch[ci][k];
+        }
+#pragma unroll
+      for (int k = 0; k < W; k++) arr[W * b + k] = acc[k];
     }
     SYNC();
   }
+}
+
+template <int W, class C>
+__device__ __forceinline__ void gather_up(C& c, double* arr) {
+  if (c.P->aux.maxchild <= 4) gather_up_n<W, 4>(c, arr);   // Ant torsos carry 4 legs, Bug 6, Spider 8
+  else gather_up_n<W, 8>(c, arr);
 }
 
 template <class C>
@@ -568,7 +591,52 @@ __device__ __forceinline__ void position_velocity(C& c) {
   PROF(2);
   // body velocities along each body's dof chain; a_b = sum over the body's own dofs of cdof_dot * qvel
   double cvel[6] = {0, 0, 0, 0, 0, 0};
-  if (lane >= 1 && lane < nb) {
+  if (c.L.tree_ok && lane >= 1 && lane < nb) {
+    // every body hangs off a free joint (6 dofs) plus at most two hinges (Layout::tree_ok): fixed shape, all loads of the
+    // chain's motion axes issued together instead of one round trip per chain element
+    KCONSTS();
+    const int b = lane, len = K.b_chain_len;
+    const int B = BYTE_OF(K.b_chain, 0), j6 = BYTE_OF(K.b_chain, len > 6 ? 6 : 0), j7 = BYTE_OF(K.b_chain, len > 7 ? 7 : 0);
+    const double* qvel = S(qvel);
+    double cd[8][6], qv[8], a[6] = {0, 0, 0, 0, 0, 0}, t[6];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int j = k < 6 ? B + k : (k == 6 ? j6 : j7);
+      qv[k] = qvel[j];
+#pragma unroll
+      for (int q = 0; q < 6; q++) cd[k][q] = S(cdof)[6 * j + q];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int q = 0; q < 6; q++) cvel[q] += cd[k][q] * qv[k];
+    if (K.b_chain_own & 1u) {
+#pragma unroll
+      for (int k = 3; k < 6; k++) {
+        cross_motion(t, cvel, cd[k]);
+#pragma unroll
+        for (int q = 0; q < 6; q++) a[q] += t[q] * qv[k];
+      }
+    }
+#pragma unroll
+    for (int k = 3; k < 6; k++)
+#pragma unroll
+      for (int q = 0; q < 6; q++) cvel[q] += cd[k][q] * qv[k];
+#pragma unroll
+    for (int k = 6; k < 8; k++) {
+      if (k < len) {
+        if ((K.b_chain_own >> k) & 1u) {
+          cross_motion(t, cvel, cd[k]);
+#pragma unroll
+          for (int q = 0; q < 6; q++) a[q] += t[q] * qv[k];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) cvel[q] += cd[k][q] * qv[k];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) S(abuf)[6 * b + q] = a[q];
+  } else if (lane >= 1 && lane < nb) {
     KCONSTS();
     const int b = lane;
     double a[6] = {0, 0, 0, 0, 0, 0}, cd[6];
@@ -610,10 +678,19 @@ __device__ __forceinline__ void position_velocity(C& c) {
       KCONSTS();
       const double* g = MF(opt) + SUMO_OPT_GRAVITY;
       double cacc[6] = {0, 0, 0, -g[0], -g[1], -g[2]}, t[6], t1[6];
-      for (int p = 0; p < K.b_bchain_len; p++) {
-        int kb = (K.b_bchain >> (8 * p)) & 0xFFu;
-        for (int q = 0; q < 6; q++) cacc[q] += S(abuf)[6 * kb + q];
+      double ab[MAXBCHAIN][6];
+#pragma unroll
+      for (int p = 0; p < MAXBCHAIN; p++) {   // all loads in flight; entries past the chain re-read its first body
+        const int kb = (K.b_bchain >> (8 * (p < K.b_bchain_len ? p : 0))) & 0xFFu;
+#pragma unroll
+        for (int q = 0; q < 6; q++) ab[p][q] = S(abuf)[6 * kb + q];
       }
+#pragma unroll
+      for (int p = 0; p < MAXBCHAIN; p++)
+        if (p < K.b_bchain_len) {
+#pragma unroll
+          for (int q = 0; q < 6; q++) cacc[q] += ab[p][q];
+        }
       mul_inert_vec(f, S(cinert) + 10 * b, cacc);
       mul_inert_vec(t, S(cinert) + 10 * b, cvel);
       cross_force(t1, cvel, t);
@@ -621,7 +698,7 @@ __device__ __forceinline__ void position_velocity(C& c) {
     }
   }
   SYNC();
-  gather_up(c, S(cfrc), 6);
+  gather_up<6>(c, S(cfrc));
   if (lane < nv) S(bias)[lane] = dot6(S(cdof) + 6 * lane, S(cfrc) + 6 * launder_ptr(c.kp)->d_body);
   PROF(3);
 }
@@ -632,8 +709,27 @@ __device__ __forceinline__ void mass_matrix(C& c) {
   const int lane = c.lane, nv = c.P->mdl.nv;
   // the contact records (dead by now) share the mass matrix's storage: clear it only here
   for (int i = lane; i < c.L.msize; i += WAVE) S(M)[i] = 0.0;
-  gather_up(c, S(cinert), 10);  // cinert -> composite rigid body inertia, in place (ends with a SYNC)
-  if (lane < nv) {
+  gather_up<10>(c, S(cinert));  // cinert -> composite rigid body inertia, in place (ends with a SYNC)
+  if (c.L.tree_ok && lane < nv) {
+    // ancestors of dof i in the fixed shape: the root dofs below it, the leg's hip (for an ankle), itself
+    const int i = lane, B = i >= c.L.d1 ? c.L.d1 : 0, il = i - B, nr = il < 6 ? il : 6;
+    double ci[6], buf[6], r[7][6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) ci[q] = S(cdof)[6 * i + q];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const int j = k < 6 ? B + k : i - 1;            // k == 6: the hip of an ankle dof (unused otherwise)
+#pragma unroll
+      for (int q = 0; q < 6; q++) r[k][q] = S(cdof)[6 * (j < 0 ? 0 : j) + q];
+    }
+    mul_inert_vec(buf, S(cinert) + 10 * K.d_body, ci);
+    double* Mi = S(M) + i * c.L.mld;
+    Mi[il] = dot6(ci, buf) + K.d_arm;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < nr) { const double v = dot6(r[k], buf); Mi[k] = v; S(M)[(B + k) * c.L.mld + il] = v; }
+    if (il >= 6 && (il & 1)) { const double v = dot6(r[6], buf); Mi[il - 1] = v; S(M)[(i - 1) * c.L.mld + il] = v; }
+  } else if (lane < nv) {
     const int i = lane;
     double buf[6];
     mul_inert_vec(buf, S(cinert) + 10 * K.d_body, S(cdof) + 6 * i);
@@ -1765,7 +1861,7 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.ncon = c.nlim = c.nefc = c.ndropped = c.use_prev = 0;
   c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = 0;
 #ifdef SUMO_PROFILE
-  for (int k = 0; k < 20; k++) c.prof[k] = 0;
+  for (int k = 0; k < 24; k++) c.prof[k] = 0;
   c.tprev = clock64();
 #endif
 }
@@ -1797,7 +1893,7 @@ __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
     atomicMax(stats + 6, (unsigned long long)c.st_maxnewton);
     atomicAdd(stats + 7, (unsigned long long)c.st_dropped);
 #ifdef SUMO_PROFILE
-    for (int k = 0; k < 20; k++) atomicAdd(stats + 8 + k, c.prof[k]);
+    for (int k = 0; k < 24; k++) atomicAdd(stats + 8 + k, c.prof[k]);
 #endif
   }
 }
@@ -2142,6 +2238,7 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
       int c0 = child_adr[b], c1 = child_adr[b + 1];
       K.b_nchild = c1 - c0;
       if (K.b_nchild > 8) FAIL(-22, "body %d has more than 8 children", b);
+      if (b > 0 && K.b_nchild > A.maxchild) A.maxchild = K.b_nchild;
       for (int q = 0; q < K.b_nchild; q++) K.b_child |= (unsigned long long)child[c0 + q] << (8 * q);
       K.b_bchain_len = bchain_len[b];
       for (int q = 0; q < bchain_len[b]; q++) K.b_bchain |= (unsigned)bchain[b * MAXBCHAIN + q] << (8 * q);
@@ -2544,13 +2641,13 @@ extern "C" int sumo_debug_forward(sumo_handle_t E, const double* ctrl, double* q
   return 0;
 }
 
-extern "C" int sumo_profile(sumo_handle_t E, double* out20) {  // cycle totals per phase (SUMO_PROFILE builds only)
-  if (!E || !out20) FAIL(-1, "bad arguments");
+extern "C" int sumo_profile(sumo_handle_t E, double* out24) {  // cycle totals per phase (SUMO_PROFILE builds only)
+  if (!E || !out24) FAIL(-1, "bad arguments");
   HIPCHK(hipSetDevice(E->device));
   HIPCHK(hipDeviceSynchronize());
   unsigned long long h[32];
   HIPCHK(hipMemcpy(h, E->d_stats, sizeof h, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 20; i++) out20[i] = (double)h[8 + i];
+  for (int i = 0; i < 24; i++) out24[i] = (double)h[8 + i];
   return 0;
 }
 

@@ -8,7 +8,7 @@ from robosumo_selfplay_amd.vec_env import SumoVecEnv
 
 NAMES = ["zeroM+init", "kinematics", "com+cinert+cdof", "comvel+rne+bias", "coll broad", "coll narrow", "row params",
          "Jb build", "aref", "mass matrix", "qacc_smooth", "newton warm", "newton grad", "newton H", "newton chol+solve",
-         "linesearch", "newton tail", "load", "(mj_step rest)", "epilogue"]
+         "linesearch", "newton tail", "load", "(mj_step rest)", "epilogue", "probe0", "probe1", "probe2", "probe3"]
 env_id = sys.argv[1] if len(sys.argv) > 1 else "RoboSumo-Ant-vs-Ant-v0"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 env = SumoVecEnv(env_id, num_envs=N, seed=1)
@@ -29,5 +29,7 @@ print("%s N=%d: %.2f ms/step, %.0f env-steps/s; newton/fwd %.2f contacts/fwd %.2
       (s1["newton"] - s0["newton"]) / nfwd, (s1["contacts"] - s0["contacts"]) / nfwd))
 tot = d.sum()
 for n, v in zip(NAMES, d):
+    if n.startswith("probe") and v == 0:
+        continue
     print("%-20s %12.0f cyc/forward  %5.1f%%" % (n, v / nfwd, 100 * v / tot))
 print("total cycles/forward %.0f" % (tot / nfwd))
