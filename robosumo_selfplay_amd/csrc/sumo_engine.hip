@@ -53,6 +53,7 @@ struct Aux {  // derived integer tables (built on the host in build_aux)
   int o_wpa;                                   // double table: world geom positions [3*nworld] | axes [3*nworld]
   int nc, nworld;  // collision centres: bodies 0..nbody-1, then one per world geom
   int maxchild;               // largest number of children of any body
+  int nstub;                  // jointless leaf bodies whose inertia is merged into their (effective) parent
   int nwp, wrounds, arounds;  // pairs with a static world geom (listed first), rounds of 64 for them / for the rest
 };
 
@@ -353,6 +354,9 @@ struct LaneRec {
   unsigned b_bchain;                        // body ids root -> self, one per byte
   unsigned long long b_chain;               // dof ids root -> body, one per byte
   unsigned b_chain_own, b_chain_free;       // bit p: chain[p] belongs to this body / starts a free joint
+  // inertial constants used for cinert: the body's own, or -- when jointless leaf bodies are rigidly attached to it -- those of
+  // the merged rigid body; body frame, inertia about the (merged) centre of mass as xx yy zz xy xz yz; zero for the leaves
+  double c_I[6], c_ipos[3], c_mass;
   // dof role
   double d_arm, d_damp;
   int d_body, d_pos;                        // d_pos: position of the dof in d_chain
@@ -542,21 +546,30 @@ __device__ __forceinline__ void position_velocity(C& c) {
   if (lane >= 1 && lane < nb) {
     KCONSTS();
     const int b = lane, ag = K.b_agent;
-    double qi[4], R[9], dif[3], T[9];
-    mulquat(qi, S(xquat) + 4 * b, K.b_iquat);
-    quat2mat(R, qi);
-    for (int k = 0; k < 3; k++) dif[k] = S(xipos)[3 * b + k] - S(com)[3 * ag + k];
-    for (int r = 0; r < 3; r++)
-      for (int cc = 0; cc < 3; cc++)
-        T[3 * r + cc] = R[3 * r] * K.b_inertia[0] * R[3 * cc] + R[3 * r + 1] * K.b_inertia[1] * R[3 * cc + 1] +
-                        R[3 * r + 2] * K.b_inertia[2] * R[3 * cc + 2];
-    double ms = K.b_mass;
+    double R[9], cp[3], dif[3], RI[9], T[6];
+    quat2mat(R, S(xquat) + 4 * b);
+    mulmatvec3(cp, R, K.c_ipos);
+    for (int k = 0; k < 3; k++) dif[k] = S(xpos)[3 * b + k] + cp[k] - S(com)[3 * ag + k];
+    // T = R I R^T with I = [xx xy xz; xy yy yz; xz yz zz] in the body frame
+    const double Ixx = K.c_I[0], Iyy = K.c_I[1], Izz = K.c_I[2], Ixy = K.c_I[3], Ixz = K.c_I[4], Iyz = K.c_I[5];
+    for (int r = 0; r < 3; r++) {
+      RI[3 * r] = R[3 * r] * Ixx + R[3 * r + 1] * Ixy + R[3 * r + 2] * Ixz;
+      RI[3 * r + 1] = R[3 * r] * Ixy + R[3 * r + 1] * Iyy + R[3 * r + 2] * Iyz;
+      RI[3 * r + 2] = R[3 * r] * Ixz + R[3 * r + 1] * Iyz + R[3 * r + 2] * Izz;
+    }
+    T[0] = RI[0] * R[0] + RI[1] * R[1] + RI[2] * R[2];   // xx
+    T[1] = RI[3] * R[3] + RI[4] * R[4] + RI[5] * R[5];   // yy
+    T[2] = RI[6] * R[6] + RI[7] * R[7] + RI[8] * R[8];   // zz
+    T[3] = RI[0] * R[3] + RI[1] * R[4] + RI[2] * R[5];   // xy
+    T[4] = RI[0] * R[6] + RI[1] * R[7] + RI[2] * R[8];   // xz
+    T[5] = RI[3] * R[6] + RI[4] * R[7] + RI[5] * R[8];   // yz
+    double ms = K.c_mass;
     double* res = S(cinert) + 10 * b;
     res[0] = T[0] + ms * (dif[1] * dif[1] + dif[2] * dif[2]);
-    res[1] = T[4] + ms * (dif[0] * dif[0] + dif[2] * dif[2]);
-    res[2] = T[8] + ms * (dif[0] * dif[0] + dif[1] * dif[1]);
-    res[3] = T[1] - ms * dif[0] * dif[1];
-    res[4] = T[2] - ms * dif[0] * dif[2];
+    res[1] = T[1] + ms * (dif[0] * dif[0] + dif[2] * dif[2]);
+    res[2] = T[2] + ms * (dif[0] * dif[0] + dif[1] * dif[1]);
+    res[3] = T[3] - ms * dif[0] * dif[1];
+    res[4] = T[4] - ms * dif[0] * dif[2];
     res[5] = T[5] - ms * dif[1] * dif[2];
     res[6] = ms * dif[0]; res[7] = ms * dif[1]; res[8] = ms * dif[2];
     res[9] = ms;
@@ -2088,7 +2101,37 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
   if (nb > WAVE || nv > WAVE || m->njnt > WAVE || m->nq > WAVE) FAIL(-10, "scene too large for one wavefront per env (nbody %d nv %d)", nb, nv);
   if (m->nagent != 2) FAIL(-11, "exactly two agents expected");
   if (nv != 28 && nv != 32 && nv != 36 && nv != 40 && nv != 44) FAIL(-18, "no kernel variant for nv=%d", nv);
-  const int* parent = SUMO_I(m, body_parentid);
+  const int* tparent = SUMO_I(m, body_parentid);
+  // "Effective" tree of the kernel's level-by-level passes: a body whose parent carries no joint is re-attached to the nearest
+  // ancestor that does, with the static transforms composed (the jointless body keeps its own frame as a leaf: its frame
+  // still feeds its geom and inertia, and subtree sums do not care which rigidly connected ancestor collects it).  For the
+  // RoboSumo agents (torso -> jointless leg stub -> hip body -> ankle body) this removes one level from every pass.
+  std::vector<int> eparent(nb, 0);
+  std::vector<double> epos(3 * (size_t)nb, 0.0), equat(4 * (size_t)nb, 0.0);
+  for (int b = 0; b < nb; b++) {
+    double pos[3] = {SUMO_F(m, body_pos)[3 * b], SUMO_F(m, body_pos)[3 * b + 1], SUMO_F(m, body_pos)[3 * b + 2]};
+    double q[4] = {SUMO_F(m, body_quat)[4 * b], SUMO_F(m, body_quat)[4 * b + 1], SUMO_F(m, body_quat)[4 * b + 2], SUMO_F(m, body_quat)[4 * b + 3]};
+    int pp = b ? tparent[b] : 0;
+    while (pp != 0 && SUMO_I(m, body_jntnum)[pp] == 0) {
+      const double* pq = SUMO_F(m, body_quat) + 4 * pp;
+      const double* ppos = SUMO_F(m, body_pos) + 3 * pp;
+      double R[9];
+      quat2mat_h(R, pq);
+      double np_[3] = {ppos[0] + R[0] * pos[0] + R[1] * pos[1] + R[2] * pos[2], ppos[1] + R[3] * pos[0] + R[4] * pos[1] + R[5] * pos[2],
+                       ppos[2] + R[6] * pos[0] + R[7] * pos[1] + R[8] * pos[2]};
+      double nq[4] = {pq[0] * q[0] - pq[1] * q[1] - pq[2] * q[2] - pq[3] * q[3], pq[0] * q[1] + pq[1] * q[0] + pq[2] * q[3] - pq[3] * q[2],
+                      pq[0] * q[2] - pq[1] * q[3] + pq[2] * q[0] + pq[3] * q[1], pq[0] * q[3] + pq[1] * q[2] - pq[2] * q[1] + pq[3] * q[0]};
+      double nn = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+      for (int k = 0; k < 3; k++) pos[k] = np_[k];
+      for (int k = 0; k < 4; k++) q[k] = nq[k] / nn;
+      pp = tparent[pp];
+    }
+    eparent[b] = pp;
+    for (int k = 0; k < 3; k++) epos[3 * b + k] = pos[k];
+    for (int k = 0; k < 4; k++) equat[4 * b + k] = q[k];
+  }
+  const int* parent = getenv("SUMO_TRUE_TREE") && atoi(getenv("SUMO_TRUE_TREE")) ? tparent : eparent.data();
+  const bool folded = parent != tparent;
   std::vector<int> depth(nb, 0);
   int ndepth = 1;
   for (int b = 1; b < nb; b++) { depth[b] = depth[parent[b]] + 1; if (depth[b] + 1 > ndepth) ndepth = depth[b] + 1; }
@@ -2098,8 +2141,21 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
   std::vector<int> lvl_adr(ndepth + 1, 0), lvl_body;
   for (int d = 0; d < ndepth; d++) { lvl_adr[d] = (int)lvl_body.size(); for (int b = 0; b < nb; b++) if (depth[b] == d) lvl_body.push_back(b); }
   lvl_adr[ndepth] = (int)lvl_body.size();
+  // jointless leaves of the effective tree ("stubs", e.g. the fixed upper leg segments): rigidly attached to their parent, so
+  // their inertia is added to the parent's once per evaluation and they take no part in the subtree gathers
+  std::vector<int> is_stub(nb, 0);
+  if (folded)
+    for (int b = 1; b < nb; b++) {
+      if (SUMO_I(m, body_jntnum)[b] != 0 || parent[b] == 0) continue;
+      bool leaf = true;
+      for (int ch = 1; ch < nb; ch++) if (ch != b && parent[ch] == b) leaf = false;
+      is_stub[b] = leaf;
+    }
   std::vector<int> child_adr(nb + 1, 0), child;
-  for (int b = 0; b < nb; b++) { child_adr[b] = (int)child.size(); for (int ch = nb - 1; ch > b; ch--) if (parent[ch] == b && b != 0) child.push_back(ch); }
+  for (int b = 0; b < nb; b++) {
+    child_adr[b] = (int)child.size();
+    for (int ch = nb - 1; ch > b; ch--) if (parent[ch] == b && b != 0 && !is_stub[ch]) child.push_back(ch);
+  }
   child_adr[nb] = (int)child.size();
   std::vector<int> chain_len(nb, 0), chain(nb * MAXCHAIN, -1), bchain_len(nb, 0), bchain(nb * MAXBCHAIN, -1), body_agent(nb, -1);
   pic.assign((size_t)nb * nv, -1);
@@ -2113,7 +2169,7 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
     bchain_len[b] = (int)bc.size();
     for (size_t i = 0; i < bc.size(); i++) bchain[b * MAXBCHAIN + i] = bc[i];
     int bb = b;
-    while (bb && dofnum[bb] == 0) bb = parent[bb];
+    while (bb && dofnum[bb] == 0) bb = tparent[bb];
     std::vector<int> dc;
     if (bb) for (int d = dofadr[bb] + dofnum[bb] - 1; d >= 0; d = dpar[d]) dc.insert(dc.begin(), d);
     if ((int)dc.size() > MAXCHAIN) FAIL(-13, "dof chain longer than %d", MAXCHAIN);
@@ -2222,8 +2278,8 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
     K.b_jnt = -1; K.b_level = -1; K.b_agent = 0;
     if (l < nb) {
       int b = l;
-      for (int k = 0; k < 3; k++) { K.b_pos[k] = SUMO_F(m, body_pos)[3 * b + k]; K.b_ipos[k] = SUMO_F(m, body_ipos)[3 * b + k]; K.b_inertia[k] = SUMO_F(m, body_inertia)[3 * b + k]; }
-      for (int k = 0; k < 4; k++) { K.b_quat[k] = SUMO_F(m, body_quat)[4 * b + k]; K.b_iquat[k] = SUMO_F(m, body_iquat)[4 * b + k]; }
+      for (int k = 0; k < 3; k++) { K.b_pos[k] = folded ? epos[3 * b + k] : SUMO_F(m, body_pos)[3 * b + k]; K.b_ipos[k] = SUMO_F(m, body_ipos)[3 * b + k]; K.b_inertia[k] = SUMO_F(m, body_inertia)[3 * b + k]; }
+      for (int k = 0; k < 4; k++) { K.b_quat[k] = folded ? equat[4 * b + k] : SUMO_F(m, body_quat)[4 * b + k]; K.b_iquat[k] = SUMO_F(m, body_iquat)[4 * b + k]; }
       K.b_mass = SUMO_F(m, body_mass)[b];
       K.b_parent = parent[b]; K.b_level = depth[b]; K.b_agent = body_agent[b] < 0 ? 0 : body_agent[b];
       int jn = SUMO_I(m, body_jntnum)[b], ja = SUMO_I(m, body_jntadr)[b];
@@ -2239,6 +2295,45 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
       K.b_nchild = c1 - c0;
       if (K.b_nchild > 8) FAIL(-22, "body %d has more than 8 children", b);
       if (b > 0 && K.b_nchild > A.maxchild) A.maxchild = K.b_nchild;
+      {  // inertial constants for cinert: own, merged with the rigidly attached leaves, or zero for such a leaf
+        auto add_part = [&](double* I6, double* mc, double& M, double mass, const double* cpos, const double* Rb, const double* diag) {
+          // accumulates mass, mass * centre and the inertia about the ORIGIN of the body frame (shifted to the centre below)
+          double Ip[9];
+          for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++)
+            Ip[3 * r + cc] = Rb[3 * r] * diag[0] * Rb[3 * cc] + Rb[3 * r + 1] * diag[1] * Rb[3 * cc + 1] + Rb[3 * r + 2] * diag[2] * Rb[3 * cc + 2];
+          double d2 = cpos[0] * cpos[0] + cpos[1] * cpos[1] + cpos[2] * cpos[2];
+          I6[0] += Ip[0] + mass * (d2 - cpos[0] * cpos[0]); I6[1] += Ip[4] + mass * (d2 - cpos[1] * cpos[1]); I6[2] += Ip[8] + mass * (d2 - cpos[2] * cpos[2]);
+          I6[3] += Ip[1] - mass * cpos[0] * cpos[1]; I6[4] += Ip[2] - mass * cpos[0] * cpos[2]; I6[5] += Ip[5] - mass * cpos[1] * cpos[2];
+          for (int k = 0; k < 3; k++) mc[k] += mass * cpos[k];
+          M += mass;
+        };
+        double I6[6] = {0, 0, 0, 0, 0, 0}, mc[3] = {0, 0, 0}, M = 0, Rb[9];
+        if (!is_stub[b]) {
+          quat2mat_h(Rb, SUMO_F(m, body_iquat) + 4 * b);
+          add_part(I6, mc, M, SUMO_F(m, body_mass)[b], SUMO_F(m, body_ipos) + 3 * b, Rb, SUMO_F(m, body_inertia) + 3 * b);
+          for (int sb = 1; sb < nb; sb++)
+            if (is_stub[sb] && parent[sb] == b) {
+              double Rs[9], Ri[9], Rsi[9], cs[3];
+              quat2mat_h(Rs, &equat[4 * sb]);
+              quat2mat_h(Ri, SUMO_F(m, body_iquat) + 4 * sb);
+              for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++)
+                Rsi[3 * r + cc] = Rs[3 * r] * Ri[cc] + Rs[3 * r + 1] * Ri[3 + cc] + Rs[3 * r + 2] * Ri[6 + cc];
+              const double* ip = SUMO_F(m, body_ipos) + 3 * sb;
+              for (int k = 0; k < 3; k++) cs[k] = epos[3 * sb + k] + Rs[3 * k] * ip[0] + Rs[3 * k + 1] * ip[1] + Rs[3 * k + 2] * ip[2];
+              add_part(I6, mc, M, SUMO_F(m, body_mass)[sb], cs, Rsi, SUMO_F(m, body_inertia) + 3 * sb);
+              A.nstub++;
+            }
+          double cm[3] = {0, 0, 0};
+          if (M > 0) for (int k = 0; k < 3; k++) cm[k] = mc[k] / M;
+          // shift from the frame origin to the (merged) centre of mass
+          double d2 = cm[0] * cm[0] + cm[1] * cm[1] + cm[2] * cm[2];
+          I6[0] -= M * (d2 - cm[0] * cm[0]); I6[1] -= M * (d2 - cm[1] * cm[1]); I6[2] -= M * (d2 - cm[2] * cm[2]);
+          I6[3] += M * cm[0] * cm[1]; I6[4] += M * cm[0] * cm[2]; I6[5] += M * cm[1] * cm[2];
+          for (int k = 0; k < 6; k++) K.c_I[k] = I6[k];
+          for (int k = 0; k < 3; k++) K.c_ipos[k] = cm[k];
+          K.c_mass = M;
+        }
+      }
       for (int q = 0; q < K.b_nchild; q++) K.b_child |= (unsigned long long)child[c0 + q] << (8 * q);
       K.b_bchain_len = bchain_len[b];
       for (int q = 0; q < bchain_len[b]; q++) K.b_bchain |= (unsigned)bchain[b * MAXBCHAIN + q] << (8 * q);
