@@ -1353,13 +1353,28 @@ __device__ __forceinline__ double tree_factor_solve(C& c, const double (&row)[8]
     double s[6], br = b;
 #pragma unroll
     for (int p = 0; p < 6; p++) s[p] = row[p];
-#pragma unroll 4
-    for (int d = B + 6; d < B + nvg; d++) {
-      const double am = ROW[8 * d + il];
-      const double* wd = WW + 6 * d;
+    // leg dofs of this agent: at most MAXLD; unrolled over the bound in batches of four with the 32 loads of a batch issued
+    // before its 28 FMAs (a leg dof past the agent's own re-reads the first one and is masked out of the sums)
+    constexpr int MAXLD = C::NV == 28 ? 8 : (C::NV == 32 ? 12 : 16);
+    const int nld = nvg - 6;
 #pragma unroll
-      for (int p = 0; p < 6; p++) s[p] -= am * wd[p];
-      br -= am * Y[d];
+    for (int k0 = 0; k0 < MAXLD; k0 += 4) {
+      double am[4], yv[4], wv[4][6];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int d = B + 6 + (k0 + k < nld ? k0 + k : 0);
+        am[k] = ROW[8 * d + il];
+        yv[k] = Y[d];
+#pragma unroll
+        for (int p = 0; p < 6; p++) wv[k][p] = WW[6 * d + p];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const double a_ = k0 + k < nld ? am[k] : 0.0;
+#pragma unroll
+        for (int p = 0; p < 6; p++) s[p] -= a_ * wv[k][p];
+        br -= a_ * yv[k];
+      }
     }
 #pragma unroll
     for (int p = 0; p < 6; p++) ROW[8 * lane + p] = s[p];
@@ -1429,7 +1444,9 @@ __device__ __forceinline__ double solver_cost(C& c, double Ma_i, double x_i) {
   return wave_sum(v);
 }
 
-template <class C>
+// TREE: every contact touches one moving body (c.htree) -- two instantiations so that the register-hungry general
+// factorisation does not share a loop (and its spills) with the common tree-sparse one
+template <bool TREE, class C>
 __device__ __forceinline__ void newton_solve(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const Aux& aux = c.P->aux;
@@ -1523,7 +1540,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
         qc += Jb[s] * cp[0] + Jb[ns + s] * cp[1] + Jb[2 * ns + s] * cp[2];
       }
       g = Ma - S(qsm)[lane] - qc;
-      if (!c.htree) S(dlim)[lane] = dl;
+      if (!TREE) S(dlim)[lane] = dl;
     }
     double gn = wave_sum(g * g);
     PROF(12);
@@ -1531,7 +1548,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
     SYNC();
     // ---- Hessian H = M + J^T diag(D_active) J, lower triangle: entry-major gather (every lane a few entries).
     // All loads of the mass-matrix / mask words are issued before any store so they pipeline.
-    if (!c.htree) {
+    if (!TREE) {
       const unsigned long long* cm = (const unsigned long long*)S(cmask);
       double hreg[C::EPL];
       unsigned long long mreg[C::EPL];
@@ -1575,7 +1592,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
     PROF(13);
     int hfail;
     double sr;
-    if (c.htree) {  // every contact touches one moving body: H keeps the tree sparsity of M (see tree_factor_solve)
+    if (TREE) {  // every contact touches one moving body: H keeps the tree sparsity of M (see tree_factor_solve)
       double row[8];
       tree_rows(c, row, dl, ncon > 0);
       sr = -tree_factor_solve(c, row, g, &hfail);
@@ -1686,7 +1703,7 @@ __device__ __forceinline__ void forward(C& c) {
   if (lane < nv) S(asmo)[lane] = as;
   SYNC();
   PROF(10);
-  newton_solve(c);
+  if (c.htree) newton_solve<true>(c); else newton_solve<false>(c);
   PROF(16);
   c.st_ncon += c.ncon;
   c.st_nefc += c.nefc;
