@@ -532,13 +532,12 @@ __device__ __forceinline__ void position_velocity(C& c) {
     double px = 0, py = 0, pz = 0;
     if (isb) { px = K.b_mass * S(xipos)[3 * lane]; py = K.b_mass * S(xipos)[3 * lane + 1]; pz = K.b_mass * S(xipos)[3 * lane + 2]; }
     const int ag = isb ? K.b_agent : -1;
-    for (int a = 0; a < mdl.nagent; a++) {
-      double sx = wave_sum(ag == a ? px : 0.0), sy = wave_sum(ag == a ? py : 0.0), sz = wave_sum(ag == a ? pz : 0.0);
-      if (lane == 0) {
-        double stm = MF(body_subtreemass)[MI(agent_torso)[a]];
-        const double istm = fast_rcp(stm);
-        S(com)[3 * a] = sx * istm; S(com)[3 * a + 1] = sy * istm; S(com)[3 * a + 2] = sz * istm;
-      }
+    // six independent wave sums (x, y, z of both agents) issued together so their DPP chains overlap
+    const double s0x = wave_sum(ag == 0 ? px : 0.0), s0y = wave_sum(ag == 0 ? py : 0.0), s0z = wave_sum(ag == 0 ? pz : 0.0);
+    const double s1x = wave_sum(ag == 1 ? px : 0.0), s1y = wave_sum(ag == 1 ? py : 0.0), s1z = wave_sum(ag == 1 ? pz : 0.0);
+    if (lane < 2) {
+      const double istm = fast_rcp(MF(body_subtreemass)[MI(agent_torso)[lane]]);
+      S(com)[3 * lane] = (lane ? s1x : s0x) * istm; S(com)[3 * lane + 1] = (lane ? s1y : s0y) * istm; S(com)[3 * lane + 2] = (lane ? s1z : s0z) * istm;
     }
   }
   SYNC();
