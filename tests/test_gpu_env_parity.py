@@ -95,7 +95,9 @@ def test_forward_dynamics_parity(env_id):
 # 20 forward evaluations amplify that: 1e-6 there, still 100x inside north_star's 1e-4.
 @pytest.mark.parametrize("env_id,steps,tol", [("RoboSumo-Ant-vs-Ant-v0", 60, 1e-9),
                                               ("RoboSumo-Spider-vs-Spider-v0", 25, 1e-6),
-                                              ("RoboSumo-Ant-vs-Spider-v0", 25, 1e-6)])
+                                              ("RoboSumo-Ant-vs-Spider-v0", 25, 1e-6),
+                                              ("RoboSumo-Bug-vs-Bug-v0", 20, 1e-6),
+                                              ("RoboSumo-Spider-vs-Bug-v0", 15, 1e-6)])
 def test_step_parity_with_resync(env_id, steps, tol):
     """Full env step (5 x RK4, rewards, done, auto-reset, obs) from identical states; the device is re-synchronised to
     the oracle state after each step so chaotic divergence cannot mask (or fake) per-step agreement."""
