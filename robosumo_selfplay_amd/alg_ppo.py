@@ -187,7 +187,7 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
             envsperbatch = nenvs // nminibatches
             envinds = np.arange(nenvs)
             flatinds = np.arange(nenvs * nsteps).reshape(nenvs, nsteps)
-            st0 = torch.as_tensor(np.asarray(states, np.float32)).to(dev)
+            st0 = states if torch.is_tensor(states) else torch.as_tensor(np.asarray(states, np.float32)).to(dev)
             b_masks = masks[0]
             for epoch in range(noptepochs):
                 np.random.shuffle(envinds)

@@ -50,14 +50,17 @@ class Runner(AbstractEnvRunner):
         if nagent != 2:
             raise ValueError("two-agent self-play only (runner.py assumes agents 0 and 1)")
         self.lam, self.gamma, self.rho_bar, self.c_bar = lam, gamma, rho_bar, c_bar
-        self.device_mode = hasattr(env, "step_device") and all(hasattr(m, "act_model") and hasattr(m.act_model, "evaluate")
-                                                               for m in models)
+        self.recurrent = all(getattr(m, "recurrent", False) for m in models)
+        self.device_mode = hasattr(env, "step_device") and (self.recurrent or all(
+            hasattr(m, "act_model") and hasattr(m.act_model, "evaluate") for m in models))
         self.device = getattr(env, "device", None) or device or torch.device("cuda", 0)
         ob_shape = env.observation_space[0].shape
         self.ob_dim = ob_shape[0]
         if self.device_mode:
             self.obs = env.reset_device()                               # [N, 2, D] float32, stays in HBM
             self.dones = torch.zeros((self.nenv, 2), dtype=torch.uint8, device=self.device)
+            if self.recurrent:                                          # recurrent states live on the device as well
+                self.states = [torch.as_tensor(np.asarray(st, np.float32)).to(self.device) for st in self.states]
         else:
             self.obs = np.zeros((self.nenv, len(env.observation_space)) + ob_shape,
                                 dtype=models[0].train_model.X.dtype.name)
@@ -113,13 +116,19 @@ class Runner(AbstractEnvRunner):
         B["done"][0, s].copy_(self.dones[:, 0])
         B["done"][1, s].copy_(self.dones[:, 1])
         o0, o1 = B["obs"][0, s], B["obs"][1, s]
-        # agent 0 acts with the learner; the opponent net scores that action (runner.py:67-85)
-        learner.evaluate(o0, PI | VF, out=dict(action=B["act"][0, s], neglogp=B["nlp"][0, s], value=B["val"][0, s]))
-        opp.evaluate(o0, PI, given_action=B["act"][0, s], out=dict(neglogp=B["onlp"][0, s], action=B["scratch_a"]))
-        # agent 1 acts with the opponent; the learner net evaluates value and neglogp there (runner.py:86-96)
-        opp.evaluate(o1, PI, out=dict(action=B["act"][1, s], neglogp=B["onlp"][1, s]))
-        learner.evaluate(o1, PI | VF, given_action=B["act"][1, s],
-                         out=dict(neglogp=B["nlp"][1, s], value=B["val"][1, s], action=B["scratch_a"]))
+        if self.recurrent:
+            # same five evaluations through the recurrent nets (runner.py:62-96 with the S / M feeds): each stream carries its
+            # acting model's state; the scoring calls without a state feed start from zeros, as the reference's calls do
+            m0, m1 = self.models
+            a0, v0, self.states[0], n0 = m0.step(o0, S=self.states[0], M=self.dones[:, 0])
+            B["act"][0, s].copy_(a0); B["val"][0, s].copy_(v0); B["nlp"][0, s].copy_(n0)
+            B["onlp"][0, s].copy_(m1.act_model.action_probability(o0, given_action=a0))
+            a1, _, self.states[1], on1 = m1.step(o1, S=self.states[1], M=self.dones[:, 1])
+            B["act"][1, s].copy_(a1); B["onlp"][1, s].copy_(on1)
+            B["val"][1, s].copy_(m0.value(o1, S=self.states[1], M=self.dones[:, 1]))
+            B["nlp"][1, s].copy_(m0.act_model.action_probability(o1, given_action=a1))
+        else:
+            self._policy_evals(B, s, learner, opp, o0, o1)
         act = env.act_dev
         act[:, 0, :].copy_(B["act"][0, s])
         act[:, 1, :].copy_(B["act"][1, s])
@@ -136,24 +145,39 @@ class Runner(AbstractEnvRunner):
         B["ep_r"][s].copy_(er)
         B["ep_l"][s].copy_(el)
 
+    def _policy_evals(self, B, s, learner, opp, o0, o1):
+        PI, VF = ppo_capi.FWD_PI, ppo_capi.FWD_VF
+        # agent 0 acts with the learner; the opponent net scores that action (runner.py:67-85)
+        learner.evaluate(o0, PI | VF, out=dict(action=B["act"][0, s], neglogp=B["nlp"][0, s], value=B["val"][0, s]))
+        opp.evaluate(o0, PI, given_action=B["act"][0, s], out=dict(neglogp=B["onlp"][0, s], action=B["scratch_a"]))
+        # agent 1 acts with the opponent; the learner net evaluates value and neglogp there (runner.py:86-96)
+        opp.evaluate(o1, PI, out=dict(action=B["act"][1, s], neglogp=B["onlp"][1, s]))
+        learner.evaluate(o1, PI | VF, given_action=B["act"][1, s],
+                         out=dict(neglogp=B["nlp"][1, s], value=B["val"][1, s], action=B["scratch_a"]))
+
     def _run_device(self, update):
         t = self._t
         T, N = self.nsteps, self.nenv
         B = self._alloc_device(T)
         alpha = anneal_alpha(update, self.anneal_bound)
+        states0 = self.states[0].clone() if self.recurrent else None     # BPTT starts from the rollout's initial state
         for s in range(T):
             self._step_device(B, s, alpha)
         learner = self.models[0].act_model
         last_values = t.empty((2, N), dtype=t.float32, device=self.device)
-        learner.evaluate(self.obs[:, 0, :], ppo_capi.FWD_VF, out=dict(value=last_values[0]))   # runner.py:184: always models[0]
-        learner.evaluate(self.obs[:, 1, :], ppo_capi.FWD_VF, out=dict(value=last_values[1]))
+        if self.recurrent:
+            for g in range(2):
+                last_values[g].copy_(self.models[0].value(self.obs[:, g, :], S=self.states[g], M=self.dones[:, g]))
+        else:
+            learner.evaluate(self.obs[:, 0, :], ppo_capi.FWD_VF, out=dict(value=last_values[0]))   # runner.py:184: always models[0]
+            learner.evaluate(self.obs[:, 1, :], ppo_capi.FWD_VF, out=dict(value=last_values[1]))
         returns, opr, oer, ratio = self._vtrace(B["rew"], B["val"], B["nlp"], B["onlp"], B["done"], self.dones.contiguous(), last_values)
         # episode infos of agent 0 (monitor.py:63-78), harvested with one host sync per rollout
         d = B["ep_done"].cpu().numpy().astype(bool)
         rr, ll = B["ep_r"].cpu().numpy(), B["ep_l"].cpu().numpy()
         epinfos = [{"r": round(float(rr[s, e]), 6), "l": int(ll[s, e]), "t": 0.0} for s, e in zip(*np.nonzero(d))]
         return (sf01(B["obs"]), sf01(returns), sf01(B["done"].bool()), sf01(B["act"]), sf01(B["val"]), sf01(B["nlp"]), sf01(B["rew"]),
-                sf01(B["onlp"]), sf01(B["obs"][1]), sf01(B["act"][1]), None, epinfos, sf0(opr), sf0(oer), sf0(ratio))
+                sf01(B["onlp"]), sf01(B["obs"][1]), sf01(B["act"][1]), states0, epinfos, sf0(opr), sf0(oer), sf0(ratio))
 
     # ---- host mode ----------------------------------------------------------------------------------------------
     def _run_host(self, update):

@@ -104,3 +104,36 @@ def test_learn_with_lstm_policy_smoke(tmp_path):
     assert torch.isfinite(model.params).all()
     assert len(os.listdir(os.path.join(str(tmp_path), "checkpoints"))) == 3
     env.close()
+
+
+def test_device_and_host_recurrent_rollouts_agree():
+    """The device-mode recurrent Runner (states, masks and buffers stay in HBM) reproduces the host-mode one, which follows the
+    reference Runner line by line (runner.py:62-151 with the S / M feeds)."""
+    from robosumo_selfplay_amd.runner import Runner
+
+    class HostOnly(object):                      # hides step_device so that the Runner takes the reference (numpy) path
+        def __init__(self, env):
+            self._e = env
+            self.num_envs, self.observation_space, self.action_space = env.num_envs, env.observation_space, env.action_space
+        def reset(self):
+            return self._e.reset()
+        def step(self, a):
+            return self._e.step(a)
+
+    outs = []
+    for host in (False, True):
+        env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=8, seed=12)
+        np.random.seed(6)
+        spec = lstm_model.LstmSpec(121, 8, 64)
+        ms = [lstm_model.LstmPPOModel(policy=spec, nbatch_act=8, nsteps=6, trainable=(i == 0)) for i in range(2)]
+        ms[1].set_param_list([p + 0.01 for p in ms[0].get_param_list()])
+        for i, m in enumerate(ms):
+            m.seed(100 + i)
+        r = Runner(env=HostOnly(env) if host else env, models=ms, nsteps=6, nagent=2, gamma=0.99, lam=0.95, rho_bar=1.0, c_bar=1.0)
+        assert r.device_mode == (not host)
+        out = r.run(1)
+        cv = lambda x: x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+        outs.append([cv(out[k]) for k in (0, 1, 3, 4, 5, 7, 10)])
+        env.close()
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-5, atol=1e-6), np.abs(a - b).max()
