@@ -37,7 +37,7 @@ extern "C" {
 typedef struct sumo_engine* sumo_handle_t;
 
 #define SUMO_INFO_STRIDE 8
-#define SUMO_NDIMS 16 /* nq nv nu nbody njnt ngeom npair nagent obs_stride act_stride maxcon maxefc lds_bytes state_stride 0 0 */
+#define SUMO_NDIMS 16 /* nq nv nu nbody njnt ngeom npair nagent obs_stride act_stride maxcon maxefc lds_bytes state_stride jbcap 0 */
 
 const char* sumo_last_error(void);
 int sumo_create(const void* model_blob, size_t nbytes, int num_envs, int device, sumo_handle_t* out);

@@ -32,7 +32,7 @@ def lib():
         L.so_destroy.argtypes = [C.c_void_p]
         L.so_last_error.restype = C.c_char_p
         for name in ("so_dims", "so_reset", "so_step", "so_get_state", "so_set_state", "so_forward", "so_mj_step",
-                     "so_get_array", "so_stats", "so_set_maxcon", "so_set_seeds"):
+                     "so_get_array", "so_stats", "so_set_maxcon", "so_set_jbcap", "so_set_seeds"):
             getattr(L, name).restype = C.c_int
         _LIB = L
     return _LIB
@@ -45,7 +45,7 @@ def _p(a):
 class OracleSim:
     """N independent envs stepped serially (or with OpenMP threads) in float64."""
 
-    def __init__(self, model, num_envs, maxcon=None):
+    def __init__(self, model, num_envs, maxcon=None, jbcap=None):
         self.L = lib()
         blob = model.to_blob()
         self._blob = (C.c_char * len(blob)).from_buffer_copy(blob)
@@ -60,6 +60,8 @@ class OracleSim:
         self.N = int(num_envs)
         if maxcon is not None:
             assert self.L.so_set_maxcon(self.h, int(maxcon)) == 0
+        if jbcap is not None:
+            assert self.L.so_set_jbcap(self.h, int(jbcap)) == 0
 
     def __del__(self):
         try:

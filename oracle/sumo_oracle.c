@@ -59,7 +59,7 @@ typedef struct {
 struct so_sim {
   void* blob;
   sumo_model_t m;
-  int N, maxcon, maxefc, obs_stride, act_stride;
+  int N, maxcon, jbcap, maxefc, obs_stride, act_stride;
   env_t* env;
 };
 
@@ -522,12 +522,12 @@ static void collision(const so_sim* s, env_t* d) {
       c->g1 = g1; c->g2 = g2;
     }
   }
-  /* The HIP engine keeps contact Jacobians in a pool of maxcon + maxcon/3 "halves" (one per moving body of a contact):
+  /* The HIP engine keeps contact Jacobians in a pool of `jbcap` "halves" (one per moving body of a contact; sumo_dims):
    * the first contact, in pair order, that does not fit and all later ones are dropped and counted.  Mirrored here so the
-   * two stay comparable when the pool overflows (only with > 16 simultaneous contacts between moving bodies). */
+   * two stay comparable when the pool overflows (many simultaneous contacts between moving bodies).  jbcap 0 = no pool limit. */
   {
     const int* gbody = SUMO_I(m, geom_bodyid);
-    int cap = s->maxcon + s->maxcon / 3, used = 0;
+    int cap = s->jbcap > 0 ? s->jbcap : 2 * s->maxcon, used = 0;
     for (int i = 0; i < d->ncon; i++) {
       int nh = (gbody[d->con[i].g1] != 0 && gbody[d->con[i].g2] != 0) ? 2 : 1;
       if (used + nh > cap) { d->ncon_dropped += d->ncon - i; d->ncon = i; break; }
@@ -1148,6 +1148,11 @@ int so_dims(const so_sim* s, int* o) {
   return 0;
 }
 
+int so_set_jbcap(so_sim* s, int jbcap) {
+  if (jbcap < 0) return -1;
+  s->jbcap = jbcap;
+  return 0;
+}
 int so_set_maxcon(so_sim* s, int maxcon) {
   if (maxcon < 1 || maxcon > MAXCON_CAP) return -1;
   s->maxcon = maxcon;

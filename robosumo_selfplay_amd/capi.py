@@ -74,7 +74,7 @@ class Engine:
         d = np.zeros(NDIMS, np.int32)
         _chk(L.sumo_dims(self.h, _np(d)))
         (self.nq, self.nv, self.nu, self.nbody, self.njnt, self.ngeom, self.npair, self.nagent, self.obs_stride,
-         self.act_stride, self.maxcon, self.maxefc, self.lds_bytes, self.state_stride) = [int(x) for x in d[:14]]
+         self.act_stride, self.maxcon, self.maxefc, self.lds_bytes, self.state_stride, self.jbcap) = [int(x) for x in d[:15]]
 
     def close(self):
         if getattr(self, "h", None):

@@ -32,6 +32,9 @@
 #define SUMO_WPE 2  /* waves per SIMD the register allocator targets: 2 -> at most 256 registers per lane */
 #endif
 #define MINVAL 1e-15
+#ifndef SUMO_STAT_LDS
+#define SUMO_STAT_LDS 0
+#endif
 #define MAXCHAIN 8   /* dofs on the path root -> body (free joint 6 + hip + ankle) */
 #define MAXBCHAIN 4  /* bodies on the path root -> body */
 #define PI_D 3.14159265358979323846
@@ -73,14 +76,14 @@ struct Layout {  // LDS offsets in doubles unless noted
   int stash;     // 4 doubles parked across the step loop
   int cmask;     // per dof: 64-bit mask of the contacts whose Jacobian touches the dof
   int cond, Jb, cpar, cW, cp, jar, D, aref;
-  int limD, limA;  // joint-limit slots, dof-indexed: [nv] lower side | [nv] upper side (D = 0: side not active)
+  int limD, limA;  // joint-limit slots, hinge-indexed: [nhinge] lower side | [nhinge] upper side (D = 0: side not active)
+  int nhinge;
   int stat_d;    // static double tables: csize[2*nc] | cinvw[nc] | wbox[12*nworld] | wlim[6*nworld]
   int i_base;  // start of int region (in doubles)
   // int region offsets (in ints, relative to int base)
   int con_b;
   int b_dofidx;  // byte offset (relative to int base): signed char [16 * maxcon], dof of each Jacobian slot or -1
   int stat_i;    // static int tables: ctype[nc] | cbody[nc] | chain[2*nbody] | chlen_agent[nbody]
-  int b_slotof;  // byte offset (relative to int base, in bytes)
   int total_bytes;
 };
 
@@ -364,6 +367,7 @@ struct LaneRec {
   // joint role
   double jt_lo, jt_hi, jt_margin, jt_invw;
   int jt_type, jt_qadr, jt_dadr, jt_limited, jt_body, jt_agent;
+  int jt_hid, d_hid;                        // running index of the hinge (joint role / dof role), -1 for free-joint dofs
   // actuator role
   double a_gear, a_lo, a_hi;
   int a_dof, pad_;
@@ -390,6 +394,7 @@ struct Ctx {
   int* si;       // LDS int region
   unsigned char* sb;  // LDS byte region (slotof)
   int lane;
+  int hid, dpos;   // this lane's dof: hinge index (-1: none) and position in its body's dof chain
   // per-forward scalars (wave-uniform)
   int ncon, nlim, nefc, ndropped, use_prev, htree;  // htree: every contact has one moving body -> H is tree-sparse like M
 #ifdef SUMO_PROFILE
@@ -758,14 +763,24 @@ __device__ __forceinline__ void mass_matrix(C& c) {
 // ---- collision ---------------------------------------------------------------------------------------------
 // "centre" index of a geom: its body id for agent geoms (one geom per moving body), nbody + w for world geom w.
 // Positions / axes of all centres live in the xipos / gaxis arrays (world entries are written once per launch).
-#define CTYPE(ci) (c.si[c.L.stat_i + (ci)])
-#define CBODY(ci) (c.si[c.L.stat_i + c.P->aux.nc + (ci)])
-#define CSIZE(ci) (c.sm + c.L.stat_d + 2 * (ci))
-#define CINVW(ci) (c.sm[c.L.stat_d + 2 * c.P->aux.nc + (ci)])
-#define WBOX(w) (c.sm + c.L.stat_d + 3 * c.P->aux.nc + 12 * (w))
-#define WLIM(w) (c.sm + c.L.stat_d + 3 * c.P->aux.nc + 12 * c.P->aux.nworld + 6 * (w))
-#define CHAINW(b) (c.si + c.L.stat_i + 2 * c.P->aux.nc + 2 * (b))
-#define CHLEN_AGENT(b) (c.si[c.L.stat_i + 2 * c.P->aux.nc + 2 * c.P->mdl.nbody + (b)])
+// The static collision tables (centre types / bodies / sizes, body invweights, world-geom frames and extents, dof chains)
+// stay in device memory: a few hundred bytes that every wave of the CU reads (L1-resident).  SUMO_STAT_LDS=1 keeps them in
+// LDS instead (2.2 KB per env for the Ant scene, which costs the seventh wave per CU).
+#if SUMO_STAT_LDS
+#define STAT_I(k) (c.si[c.L.stat_i + (k)])
+#define STAT_D(k) (c.sm + c.L.stat_d + (k))
+#else
+#define STAT_I(k) (c.P->aux.ai[c.P->aux.o_stat_i + (k)])
+#define STAT_D(k) (c.P->aux.af + c.P->aux.o_stat_d + (k))
+#endif
+#define CTYPE(ci) STAT_I(ci)
+#define CBODY(ci) STAT_I(c.P->aux.nc + (ci))
+#define CSIZE(ci) STAT_D(2 * (ci))
+#define CINVW(ci) (STAT_D(2 * c.P->aux.nc + (ci))[0])
+#define WBOX(w) STAT_D(3 * c.P->aux.nc + 12 * (w))
+#define WLIM(w) STAT_D(3 * c.P->aux.nc + 12 * c.P->aux.nworld + 6 * (w))
+#define CHAINW(b) (&STAT_I(2 * c.P->aux.nc + 2 * (b)))
+#define CHLEN_AGENT(b) STAT_I(2 * c.P->aux.nc + 2 * c.P->mdl.nbody + (b))
 
 __device__ __forceinline__ void make_frame(double* f) {
   if (f[3] * f[3] + f[4] * f[4] + f[5] * f[5] < 0.25) {
@@ -1072,7 +1087,8 @@ __device__ __forceinline__ void make_constraint(C& c) {
       double B, kt, R = row_params(timestep, def_solref, def_solimp, dhi, jm, K.jt_invw, &B, &kt);
       D1 = fast_rcp(R); A1 = B * vel - kt;     // row = -e_dof: efc_vel = -qvel
     }
-    S(limD)[dof] = D0; S(limD)[nv + dof] = D1; S(limA)[dof] = A0; S(limA)[nv + dof] = A1;
+    const int hid = K.jt_hid, nh = c.L.nhinge;
+    S(limD)[hid] = D0; S(limD)[nh + hid] = D1; S(limA)[hid] = A0; S(limA)[nh + hid] = A1;
   }
   const int nlim = __popcll(__ballot(act_lo)) + __popcll(__ballot(act_hi));
   SYNC();
@@ -1106,10 +1122,6 @@ __device__ __forceinline__ void make_constraint(C& c) {
     for (int k = 0; k < 4; k++) { int r = 4 * ci + k; S(aref)[r] = B; S(jar)[r] = kt; }
   }
   PROF(6);
-  // slot map init
-  unsigned char* slotof = c.sb + c.L.b_slotof;
-  for (int i = lane; i < ncon * nv; i += WAVE) slotof[i] = 0xFF;
-  SYNC();
   // compact contact Jacobians: 3 base rows (normal, t1, t2) x ns slots.  Two moving bodies: ns = 16 (chain of body1,
   // sign -, then chain of body2, sign +); one moving body (contact with the world): ns = 8, that body's chain only.
   for (int idx = lane; idx < ncon * 16; idx += WAVE) {
@@ -1144,7 +1156,6 @@ __device__ __forceinline__ void make_constraint(C& c) {
       t[0] += cdf[3]; t[1] += cdf[4]; t[2] += cdf[5];
       double sg = side ? 1.0 : -1.0;
       j0 = sg * dot3(cd + 4, t); j1 = sg * dot3(cd + 7, t); j2 = sg * dot3(cd + 10, t);
-      slotof[ci * nv + dof] = (unsigned char)s;
       atomicOr((unsigned long long*)S(cmask) + dof, 1ull << ci);
     }
     ((signed char*)c.sb)[c.L.b_dofidx + idx] = (signed char)dof;
@@ -1157,6 +1168,9 @@ __device__ __forceinline__ void make_constraint(C& c) {
   PROF(7);
 }
 
+// Jacobian slot of dof `d` in contact `ci`: slots are positions in the dof chain of the contact's body (second body: + 8);
+// `p` is the dof's position in its own body's chain, which is also its position in the chain of any body below it
+#define SLOT_OF(ci, d, p) ((((const signed char*)c.sb)[c.L.b_dofidx + 16 * (ci) + (p)] == (signed char)(d)) ? (p) : (p) + 8)
 // cp[3*c + a] = sum_s Jb[c][a][s] * x[dof(c,s)].  Branch-free and fully unrolled so all 16 slot loads are in flight at
 // once: Jb is exactly 0 in unused slots, so those may read any x.
 template <class C>
@@ -1188,10 +1202,10 @@ __device__ __forceinline__ double row_Jx(const C& c, int r) {
 struct LimRows { double D0, D1, A0, A1; };
 template <class C>
 __device__ __forceinline__ LimRows lim_rows(const C& c) {
-  const int nv = c.P->mdl.nv, li = c.lane < nv ? c.lane : 0;
+  const int nh = c.L.nhinge, h = c.hid < 0 ? 0 : c.hid;
   LimRows q;
-  q.D0 = c.sm[c.L.limD + li]; q.D1 = c.sm[c.L.limD + nv + li]; q.A0 = c.sm[c.L.limA + li]; q.A1 = c.sm[c.L.limA + nv + li];
-  if (c.lane >= nv) q.D0 = q.D1 = 0.0;
+  q.D0 = c.sm[c.L.limD + h]; q.D1 = c.sm[c.L.limD + nh + h]; q.A0 = c.sm[c.L.limA + h]; q.A1 = c.sm[c.L.limA + nh + h];
+  if (c.hid < 0) q.D0 = q.D1 = 0.0;     // free-joint dofs and lanes past nv carry no limit
   return q;
 }
 
@@ -1304,7 +1318,7 @@ __device__ __forceinline__ void tree_rows(C& c, double (&row)[8], double diag_ad
     for (unsigned long long mk = ((const unsigned long long*)S(cmask))[lane]; mk; mk &= mk - 1) {
       const int ci = __builtin_ctzll(mk);
       const double* Jb = S(Jb) + ((c.si + c.L.con_b)[4 * ci + 3] & 0xFFFFF);   // one moving body: 3 rows x 8 chain slots
-      const double* W = S(cW) + 6 * ci;
+      const double* W = S(cW) + 5 * ci;
       const double a0 = Jb[pos], a1 = Jb[8 + pos], a2 = Jb[16 + pos];
       const double u0 = W[0] * a0 + W[1] * a1 + W[2] * a2, u1 = W[1] * a0 + W[3] * a1, u2 = W[2] * a0 + W[4] * a2;
 #pragma unroll
@@ -1459,7 +1473,6 @@ __device__ __forceinline__ void newton_solve(C& c) {
     SYNC();
     return;
   }
-  const unsigned char* slotof = c.sb + c.L.b_slotof;
   constexpr int RPL = C::NV <= 36 ? 2 : 3;   // contact rows per lane: 4 * maxcon <= 64 * RPL (build_layout)
   // ---- warm start: better of qacc_warmstart (or, in warm_mode 1, the previous RK stage's qacc still held in x) and
   // qacc_smooth
@@ -1514,7 +1527,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
       cp[0] = ((f[0] + f[1]) + f[2]) + f[3];
       cp[1] = mu * (f[0] - f[1]);
       cp[2] = mu * (f[2] - f[3]);
-      double* W = S(cW) + 6 * ci;
+      double* W = S(cW) + 5 * ci;
       W[0] = ((dact[0] + dact[1]) + dact[2]) + dact[3];
       W[1] = mu * (dact[0] - dact[1]);
       W[2] = mu * (dact[2] - dact[3]);
@@ -1532,7 +1545,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
       if (j1 < 0) { qc += lq.D1 * j1; dl += lq.D1; }   // row -e_dof
       for (unsigned long long mk = ((const unsigned long long*)S(cmask))[lane]; mk; mk &= mk - 1) {
         int ci = __builtin_ctzll(mk);
-        int s = slotof[ci * nv + lane];
+        const int s = SLOT_OF(ci, lane, c.dpos);
         const int info = (c.si + c.L.con_b)[4 * ci + 3], ns = (info >> 20) ? 16 : 8;
         const double* Jb = S(Jb) + (info & 0xFFFFF);
         const double* cp = S(cp) + 3 * ci;
@@ -1554,8 +1567,13 @@ __device__ __forceinline__ void newton_solve(C& c) {
       // (the entry words are made opaque here so that the addresses derived from them are computed in this rarely taken
       // block instead of being hoisted to kernel entry and kept in registers / scratch for the whole launch)
       unsigned ent[C::EPL];
+      int pi[C::EPL], pj[C::EPL];   // chain positions of the entry's two dofs (slot lookup, SLOT_OF)
 #pragma unroll
-      for (int m = 0; m < C::EPL; m++) { ent[m] = c.ent[m]; asm volatile("" : "+v"(ent[m])); }
+      for (int m = 0; m < C::EPL; m++) {
+        ent[m] = c.ent[m]; asm volatile("" : "+v"(ent[m]));
+        const unsigned e = ent[m] == 0xFFFFu ? 0u : ent[m];
+        pi[m] = c.P->lanes[e >> 8].d_pos; pj[m] = c.P->lanes[e & 0xFF].d_pos;
+      }
 #pragma unroll
       for (int m = 0; m < C::EPL; m++) {
         unsigned e = ent[m];
@@ -1572,10 +1590,10 @@ __device__ __forceinline__ void newton_solve(C& c) {
         double h = hreg[m];
         for (unsigned long long mk = mreg[m]; mk; mk &= mk - 1) {
           int ci = __builtin_ctzll(mk);
-          int si = slotof[ci * nv + i], sj = slotof[ci * nv + jj];
+          const int si = SLOT_OF(ci, i, pi[m]), sj = SLOT_OF(ci, jj, pj[m]);
           const int info = (c.si + c.L.con_b)[4 * ci + 3], ns = (info >> 20) ? 16 : 8;
           const double* Jb = S(Jb) + (info & 0xFFFFF);
-          const double* W = S(cW) + 6 * ci;
+          const double* W = S(cW) + 5 * ci;
           double a0 = Jb[si], a1 = Jb[ns + si], a2 = Jb[2 * ns + si], b0 = Jb[sj], b1 = Jb[ns + sj], b2 = Jb[2 * ns + sj];
           h += a0 * (W[0] * b0 + W[1] * b1 + W[2] * b2) + a1 * (W[1] * b0 + W[3] * b1) + a2 * (W[2] * b0 + W[4] * b2);
         }
@@ -1878,14 +1896,17 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.prp = P->pair_rec + c.lane;
   c.pbp = P->pair_bound + c.lane;
   // static tables -> LDS (once per launch); world centres into the tail of xipos / gaxis
+#if SUMO_STAT_LDS
   for (int i = c.lane; i < P->aux.n_stat_d; i += WAVE) smem[P->L.stat_d + i] = P->aux.af[P->aux.o_stat_d + i];
   for (int i = c.lane; i < P->aux.n_stat_i; i += WAVE) c.si[P->L.stat_i + i] = P->aux.ai[P->aux.o_stat_i + i];
+#endif
   {
     const int nb = P->mdl.nbody, nw = P->aux.nworld, nc = P->aux.nc;
     const double* wpos = P->aux.af + P->aux.o_wpa;
     for (int i = c.lane; i < 3 * nw; i += WAVE) { smem[P->L.xipos + 3 * nb + i] = wpos[i]; smem[P->L.gaxis + 3 * nb + i] = wpos[3 * nw + i]; }
   }
-  for (int i = c.lane; i < 2 * P->mdl.nv; i += WAVE) { smem[P->L.limD + i] = 0.0; smem[P->L.limA + i] = 0.0; }   // free-joint dofs never get a limit
+  c.hid = c.lane < P->mdl.nv ? P->lanes[c.lane].d_hid : -1;
+  c.dpos = P->lanes[c.lane].d_pos;
   __syncthreads();
   c.ncon = c.nlim = c.nefc = c.ndropped = c.use_prev = 0;
   c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = 0;
@@ -2366,6 +2387,9 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
       int d = l, b = SUMO_I(m, dof_bodyid)[d];
       K.d_arm = SUMO_F(m, dof_armature)[d]; K.d_damp = SUMO_F(m, dof_damping)[d]; K.d_body = b;
       K.d_pos = pic[(size_t)b * nv + d];
+      K.d_hid = -1;
+      { int jt = SUMO_I(m, dof_jntid)[d];
+        if (SUMO_I(m, jnt_type)[jt] == SUMO_JNT_HINGE) { int h = 0; for (int jj = 0; jj < jt; jj++) if (SUMO_I(m, jnt_type)[jj] == SUMO_JNT_HINGE) h++; K.d_hid = h; } }
       for (int q = 0; q < chain_len[b]; q++) K.d_chain |= (unsigned long long)chain[b * MAXCHAIN + q] << (8 * q);
     }
     if (l < m->njnt) {
@@ -2374,6 +2398,8 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
       K.jt_limited = SUMO_I(m, jnt_limited)[j]; K.jt_body = jbody[j]; K.jt_agent = body_agent[jbody[j]] < 0 ? 0 : body_agent[jbody[j]];
       K.jt_lo = SUMO_F(m, jnt_range)[2 * j]; K.jt_hi = SUMO_F(m, jnt_range)[2 * j + 1]; K.jt_margin = SUMO_F(m, jnt_margin)[j];
       K.jt_invw = SUMO_F(m, dof_invweight0)[K.jt_dadr];
+      K.jt_hid = -1;
+      if (K.jt_type == SUMO_JNT_HINGE) { int h = 0; for (int jj = 0; jj < j; jj++) if (SUMO_I(m, jnt_type)[jj] == SUMO_JNT_HINGE) h++; K.jt_hid = h; }
     }
     if (l < m->nu) {
       K.a_dof = SUMO_I(m, actuator_dofid)[l]; K.a_gear = SUMO_F(m, actuator_gear)[l];
@@ -2449,7 +2475,7 @@ static void build_layout(sumo_engine* E) {
   const int hsize = o - kin0;
   // centre positions / axes: bodies (rewritten every forward) then world geoms (static)
   L.xipos = take(3 * nc); L.gaxis = take(3 * nc);
-  L.stat_d = take(E->aux.n_stat_d);
+  L.stat_d = take(SUMO_STAT_LDS ? E->aux.n_stat_d : 0);
   {
     int nv0 = SUMO_I(m, agent_nv)[0], nv1 = SUMO_I(m, agent_nv)[1];
     int mx = nv0 > nv1 ? nv0 : nv1;
@@ -2472,37 +2498,43 @@ static void build_layout(sumo_engine* E) {
     const char* nt = getenv("SUMO_NO_TREE");
     if (nt && atoi(nt)) L.tree_ok = 0;
   }
-  L.bias = take(nv); L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = 0;
-  L.search = take(nv); L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv); L.stash = take(4);
+  L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = 0;
+  L.search = take(nv); L.bias = L.search;   // the bias force is consumed (into qsm) before the solver writes its search direction
+  L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv); L.stash = take(4);
   // contact records live from the narrow phase to the Jacobian build only: they borrow the mass matrix's storage
   if (L.msize < 14 * L.maxcon) L.msize = 14 * L.maxcon;
+  if (L.msize < 12 * nb) L.msize = 12 * nb;      // ... and so do the velocity-pass temporaries (abuf, cfrc), see below
   L.M = take(L.msize);
   L.cond = L.M;
   // body frames / joint anchors / RNE temporaries are dead before the contact Jacobians are written: same storage
   {
-    L.jbcap = L.maxcon + L.maxcon / 3;
-    int jb0 = o, need = 19 * nb + 6 * nj, jbsz = 24 * L.jbcap + 16;
+    // pool of Jacobian halves (3 rows x 8 slots, one half per moving body of a contact): room for maxcon contacts with the
+    // world, or half as many between two moving bodies -- more where the frames' storage leaves space anyway
+    int need = 7 * nb + 6 * nj;
+    L.jbcap = L.maxcon;
+    if ((need - 16) / 24 > L.jbcap) L.jbcap = (need - 16) / 24;
+    { const char* jc = getenv("SUMO_JBCAP"); if (jc && atoi(jc) > 0) L.jbcap = atoi(jc); }
+    int jb0 = o, jbsz = 24 * L.jbcap + 16;
     L.Jb = take(jbsz > need ? jbsz : need);
     int q = jb0;
     L.xpos = q; q += 3 * nb; L.xquat = q; q += 4 * nb; L.xanchor = q; q += 3 * nj; L.xaxis = q; q += 3 * nj;
-    L.abuf = q; q += 6 * nb; L.cfrc = q; q += 6 * nb;
+    // velocity-pass temporaries (dead before the narrow phase writes contact records there): the mass matrix's storage
+    L.abuf = L.M; L.cfrc = L.M + 6 * nb;
   }
-  L.cpar = take(L.maxcon); L.cW = take(6 * L.maxcon);
+  L.cpar = take(L.maxcon); L.cW = take(5 * L.maxcon);
   L.cp = take(3 * L.maxcon);
   // row arrays hold the contact rows only (4 per contact); the limit rows live in the dof-indexed slots limD / limA
   L.jar = take(4 * L.maxcon); L.D = take(L.maxcon); L.aref = take(4 * L.maxcon);
-  L.limD = take(2 * nv); L.limA = take(2 * nv);
+  L.nhinge = nhinge; L.limD = take(2 * nhinge); L.limA = take(2 * nhinge);
   // queue of broad-phase survivors (ints, inside jar / aref); drained by the narrow phase before it can overflow
   L.maxcand = 8 * L.maxcon >= 192 ? 192 : (8 * L.maxcon) / WAVE * WAVE;
   L.i_base = o;
   int io = 0;
   auto itake = [&](int n) { int r = io; io += n; return r; };
   L.con_b = itake(4 * L.maxcon);
-  L.stat_i = itake(E->aux.n_stat_i);
-  L.b_slotof = io * 4;
-  int bytes_slot = (L.maxcon * nv + 15) & ~15;
-  L.b_dofidx = L.b_slotof + bytes_slot;
-  L.total_bytes = o * 8 + io * 4 + bytes_slot + 16 * L.maxcon;
+  L.stat_i = itake(SUMO_STAT_LDS ? E->aux.n_stat_i : 0);
+  L.b_dofidx = io * 4;
+  L.total_bytes = o * 8 + io * 4 + 16 * L.maxcon;
 }
 
 extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, int device, sumo_handle_t* out) {
@@ -2619,7 +2651,7 @@ extern "C" int sumo_dims(sumo_handle_t E, int32_t* o) {
   if (!E || !o) FAIL(-1, "bad arguments");
   const sumo_model_t* m = &E->hm;
   int v[SUMO_NDIMS] = {m->nq, m->nv, m->nu, m->nbody, m->njnt, m->ngeom, m->npair, m->nagent, E->obs_stride, E->act_stride,
-                       E->L.maxcon, E->L.maxefc, E->L.total_bytes, E->state_stride, 0, 0};
+                       E->L.maxcon, E->L.maxefc, E->L.total_bytes, E->state_stride, E->L.jbcap, 0};
   memcpy(o, v, sizeof v);
   return 0;
 }

@@ -25,7 +25,7 @@ class Pair:
         self.m = mjcf.load_model(env_id)
         self.N = N
         self.eng = capi.Engine(self.m, N)
-        self.ora = OracleSim(self.m, N, maxcon=self.eng.maxcon)
+        self.ora = OracleSim(self.m, N, maxcon=self.eng.maxcon, jbcap=self.eng.jbcap)
         dev = torch.device("cuda:0")
         E = self.eng
         self.obs = torch.zeros((N, 2, E.obs_stride), dtype=torch.float32, device=dev)

@@ -10,7 +10,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 m = mjcf.load_model(env_id)
 eng = capi.Engine(m, N)
 print("dims", eng.nq, eng.nv, "maxcon", eng.maxcon, "lds", eng.lds_bytes, flush=True)
-ora = OracleSim(m, N, maxcon=eng.maxcon)
+ora = OracleSim(m, N, maxcon=eng.maxcon, jbcap=eng.jbcap)
 dev = torch.device("cuda:0")
 obs = torch.zeros((N, 2, eng.obs_stride), dtype=torch.float32, device=dev)
 seeds = np.arange(N, dtype=np.uint64) + 1000
