@@ -175,17 +175,15 @@ __device__ __forceinline__ void mulmatTvec3(double* r, const double* m, const do
          z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
-// sin / cos to ~1 ulp for |x| < 1e4 (Cody-Waite reduction by pi/2 + the fdlibm kernel polynomials); the library routine,
-// whose argument reduction dominates its cost, only for larger arguments
-__device__ __forceinline__ void fast_sincos(double x, double* sn, double* cs) {
-  if (fabs(x) > 1e4) { sincos(x, sn, cs); return; }
-  const double fn = rint(x * 6.36619772367581382433e-01);
-  double r = fma(-fn, 1.57079632673412561417e+00, x);
-  r = fma(-fn, 6.07710050650619224932e-11, r);
-  const double z = r * r;
-  // (coefficients are rematerialised at each call: hoisted out of the step loop they would sit in registers / scratch for
-  // the whole launch)
-#define SC_K(name, val)                                                                                              \
+// Library transcendentals used once per env step (reset draws, push reward) are called out of line: inlined, their
+// coefficient tables are materialised in the kernel prologue and then live in registers / scratch through all twenty
+// forward-dynamics evaluations.
+__device__ __noinline__ double slow_sin(double x) { return sin(x); }
+__device__ __noinline__ double slow_cos(double x) { return cos(x); }
+__device__ __noinline__ double slow_log(double x) { return log(x); }
+__device__ __noinline__ double slow_exp(double x) { return exp(x); }
+// a floating-point constant the compiler cannot hoist (same reason)
+#define OPAQUE_F64(name, val)                                                                                        \
   double name;                                                                                                       \
   {                                                                                                                  \
     int lo_, hi_;                                                                                                    \
@@ -195,6 +193,17 @@ __device__ __forceinline__ void fast_sincos(double x, double* sn, double* cs) {
                    "i"((int)(__builtin_bit_cast(unsigned long long, (double)(val)) >> 32)));                         \
     name = __hiloint2double(hi_, lo_);                                                                               \
   }
+// sin / cos to ~1 ulp for |x| < 1e6 (Cody-Waite reduction by pi/2 + the fdlibm kernel polynomials); the library routine,
+// whose argument reduction dominates its cost, only for larger arguments
+__device__ __forceinline__ void fast_sincos(double x, double* sn, double* cs) {
+  if (fabs(x) > 1e6) { *sn = slow_sin(x); *cs = slow_cos(x); return; }   // (two-term reduction is exact below ~1.6e6)
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-fn, 1.57079632673412561417e+00, x);
+  r = fma(-fn, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  // (coefficients are rematerialised at each call: hoisted out of the step loop they would sit in registers / scratch for
+  // the whole launch)
+#define SC_K(name, val) OPAQUE_F64(name, val)
   SC_K(S1, -1.66666666666666324348e-01); SC_K(S2, 8.33333333332248946124e-03); SC_K(S3, -1.98412698298579493134e-04);
   SC_K(S4, 2.75573137070700676789e-06); SC_K(S5, -2.50507602534068634195e-08); SC_K(S6, 1.58969099521155010221e-10);
   SC_K(C1, 4.16666666666666019037e-02); SC_K(C2, -1.38888888888741095749e-03); SC_K(C3, 2.48015872894767294178e-05);
@@ -1066,8 +1075,9 @@ __device__ __forceinline__ void make_constraint(C& c) {
     SYNC();
   }
   const double timestep = MF(opt)[SUMO_OPT_TIMESTEP];
-  const double def_solref[2] = {0.02, 1.0};
-  const double def_solimp[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+  OPAQUE_F64(sr0_, 0.02); OPAQUE_F64(si0_, 0.9); OPAQUE_F64(si1_, 0.95); OPAQUE_F64(si2_, 0.001);   // MuJoCo's default solref / solimp
+  const double def_solref[2] = {sr0_, 1.0};
+  const double def_solimp[5] = {si0_, si1_, si2_, 0.5, 2.0};
   // joint limits; lane == joint id.  A hinge owns two fixed slots indexed by its dof (lower side, upper side): D = 1/R and
   // aref, with D = 0 when the side is not active (every term of the solver carries D, so absent rows cost nothing).
   // The Jacobian of a limit row is +-e_dof: the dof's own lane evaluates its rows without touching LDS row arrays.
@@ -1824,8 +1834,8 @@ __device__ __forceinline__ void reset_state(C& c, uint64_t seed, uint32_t rc) {
     double phi = 2.0 * PI_D * rng_uniform(seed, rc, 0);
     double ang = phi + lane * (2.0 * PI_D / 2.0);
     int qa = MI(agent_qposadr)[lane];
-    S(qpos)[qa] = 1.15 * cos(ang);
-    S(qpos)[qa + 1] = 1.15 * sin(ang);
+    S(qpos)[qa] = 1.15 * slow_cos(ang);
+    S(qpos)[qa + 1] = 1.15 * slow_sin(ang);
     S(qpos)[qa + 2] = 1.25;
   }
   SYNC();
@@ -1833,8 +1843,8 @@ __device__ __forceinline__ void reset_state(C& c, uint64_t seed, uint32_t rc) {
   if (lane < nv) {
     double u1 = rng_uniform(seed, rc, RNG_NORMAL_BASE + 2 * (lane >> 1));
     double u2 = rng_uniform(seed, rc, RNG_NORMAL_BASE + 2 * (lane >> 1) + 1);
-    double rr = sqrt(-2.0 * log(1.0 - u1));
-    double z = (lane & 1) ? rr * sin(2.0 * PI_D * u2) : rr * cos(2.0 * PI_D * u2);
+    double rr = sqrt(-2.0 * slow_log(1.0 - u1));
+    double z = (lane & 1) ? rr * slow_sin(2.0 * PI_D * u2) : rr * slow_cos(2.0 * PI_D * u2);
     S(qvel)[lane] = 0.1 * z;
     S(warm)[lane] = 0.0;
   }
@@ -2012,7 +2022,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
     dir[0] /= nrm; dir[1] /= nrm;
     double proj = mv[0] * dir[0] + mv[1] * dir[1];
     double move = (proj > 0 ? proj : 0.0) * 0.1;
-    double push = -10.0 * exp(-sqrt(after[o][0] * after[o][0] + after[o][1] * after[o][1]));
+    double push = -10.0 * slow_exp(-sqrt(after[o][0] * after[o][0] + after[o][1] * after[o][1]));
     double shaping = ctrl_r + push + move;
     inf[g][0] = ctrl_r; inf[g][1] = lose; inf[g][2] = win; inf[g][3] = main_r; inf[g][4] = move; inf[g][5] = push;
     inf[g][6] = shaping; inf[g][7] = (double)flags;
