@@ -50,6 +50,7 @@ class Runner(AbstractEnvRunner):
         if nagent != 2:
             raise ValueError("two-agent self-play only (runner.py assumes agents 0 and 1)")
         self.lam, self.gamma, self.rho_bar, self.c_bar = lam, gamma, rho_bar, c_bar
+        self._side = None
         self.recurrent = all(getattr(m, "recurrent", False) for m in models)
         self.device_mode = hasattr(env, "step_device") and (self.recurrent or all(
             hasattr(m, "act_model") and hasattr(m.act_model, "evaluate") for m in models))
@@ -102,6 +103,7 @@ class Runner(AbstractEnvRunner):
         B["ep_r"] = t.empty((T, N), dtype=t.float64, device=dev)
         B["ep_l"] = t.empty((T, N), dtype=t.int32, device=dev)
         B["scratch_a"] = t.empty((N, A), dtype=f32, device=dev)
+        B["scratch_b"] = t.empty((N, A), dtype=f32, device=dev)
         return B
 
     def _step_device(self, B, s, alpha, env_events=None):
@@ -111,10 +113,8 @@ class Runner(AbstractEnvRunner):
         learner, opp = self.models[0].act_model, self.models[1].act_model
         PI, VF = ppo_capi.FWD_PI, ppo_capi.FWD_VF
         ob = self.obs                                                    # [N, 2, D] view of the env's buffer
-        B["obs"][0, s].copy_(ob[:, 0, :])
-        B["obs"][1, s].copy_(ob[:, 1, :])
-        B["done"][0, s].copy_(self.dones[:, 0])
-        B["done"][1, s].copy_(self.dones[:, 1])
+        B["obs"][:, s].copy_(ob.permute(1, 0, 2))                        # one strided copy per array instead of one per agent
+        B["done"][:, s].copy_(self.dones.t())
         o0, o1 = B["obs"][0, s], B["obs"][1, s]
         if self.recurrent:
             # same five evaluations through the recurrent nets (runner.py:62-96 with the S / M feeds): each stream carries its
@@ -130,8 +130,7 @@ class Runner(AbstractEnvRunner):
         else:
             self._policy_evals(B, s, learner, opp, o0, o1)
         act = env.act_dev
-        act[:, 0, :].copy_(B["act"][0, s])
-        act[:, 1, :].copy_(B["act"][1, s])
+        act.copy_(B["act"][:, s].permute(1, 0, 2))
         if env_events is not None:
             env_events[0].record()
         obs, info, done, er, edr, el = env.step_device(act)
@@ -146,14 +145,24 @@ class Runner(AbstractEnvRunner):
         B["ep_l"][s].copy_(el)
 
     def _policy_evals(self, B, s, learner, opp, o0, o1):
+        """The two chains (learner acts on agent 0's stream and the opponent scores it; the opponent acts on agent 1's stream
+        and the learner evaluates it) are independent: they run on two HIP streams and join before the env step."""
+        t = self._t
         PI, VF = ppo_capi.FWD_PI, ppo_capi.FWD_VF
+        cur = t.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = t.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(cur)
         # agent 0 acts with the learner; the opponent net scores that action (runner.py:67-85)
         learner.evaluate(o0, PI | VF, out=dict(action=B["act"][0, s], neglogp=B["nlp"][0, s], value=B["val"][0, s]))
         opp.evaluate(o0, PI, given_action=B["act"][0, s], out=dict(neglogp=B["onlp"][0, s], action=B["scratch_a"]))
-        # agent 1 acts with the opponent; the learner net evaluates value and neglogp there (runner.py:86-96)
-        opp.evaluate(o1, PI, out=dict(action=B["act"][1, s], neglogp=B["onlp"][1, s]))
-        learner.evaluate(o1, PI | VF, given_action=B["act"][1, s],
-                         out=dict(neglogp=B["nlp"][1, s], value=B["val"][1, s], action=B["scratch_a"]))
+        with t.cuda.stream(side):
+            # agent 1 acts with the opponent; the learner net evaluates value and neglogp there (runner.py:86-96)
+            opp.evaluate(o1, PI, out=dict(action=B["act"][1, s], neglogp=B["onlp"][1, s]))
+            learner.evaluate(o1, PI | VF, given_action=B["act"][1, s],
+                             out=dict(neglogp=B["nlp"][1, s], value=B["val"][1, s], action=B["scratch_b"]))
+        cur.wait_stream(side)
 
     def _run_device(self, update):
         t = self._t
