@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--env-id", default="RoboSumo-Ant-vs-Ant-v0")
+    ap.add_argument("--groups", type=int, default=2, help="env groups per GPU, each stepped on its own stream (1 = one launch for all envs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-envs", type=int, default=512)
     ap.add_argument("--cpu-sample-steps", type=int, default=60)
@@ -90,7 +91,7 @@ def main():
 
     model = mjcf.load_model(args.env_id)
     N = args.envs
-    env = SumoVecEnv(args.env_id, num_envs=N, seed=1000 + rank * N, device=local_rank, model=model)
+    env = SumoVecEnv(args.env_id, num_envs=N, seed=1000 + rank * N, device=local_rank, model=model, groups=args.groups)
     from robosumo_selfplay_amd import defaults
     from robosumo_selfplay_amd.model import PPOModel
     from robosumo_selfplay_amd.policies import build_policy
@@ -121,11 +122,11 @@ def main():
     for k in range(args.warmup):
         runner._step_device(B, k % ring, alpha)
     torch.cuda.synchronize(dev)
-    st0 = env.engine.stats()
+    st0 = env.stats()
     states = None
     if rank == 0 and not args.no_cpu_baseline:
         q, v, w, c = env.engine.get_state()
-        ns = min(args.cpu_sample_envs, N)
+        ns = min(args.cpu_sample_envs, env.group_size)
         states = (q[:ns].copy(), v[:ns].copy(), w[:ns].copy(), c[:ns].copy())
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -137,7 +138,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
-    st1 = env.engine.stats()
+    st1 = env.stats()
     sample_acts = [B["act"][:, k].permute(1, 0, 2).contiguous() for k in range(ring)]   # [N, 2, A] per step
 
     # ---- "+ PPO2 iters/sec": one full update, outside the timed region above
@@ -178,11 +179,11 @@ def main():
         traffic = None
         try:   # PMC traffic is collected offline with rocprofv3 (profiles/README.md); reported only for the profiled config
             pj = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")))   # newest collection
-            if ("<%d>" % model.nv) in pj["kernel"] and pj["envs"] == N:
+            if ("<%d>" % model.nv) in pj["kernel"] and pj["envs"] == env.group_size:
                 traffic = pj["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
-        achieved = B * N / (kern_ms * 1e-3) / 1e9
+        achieved = B * env.group_size / (kern_ms * 1e-3) / 1e9      # per launch: one env group (HIP events on its stream)
         nfwd = max(1.0, st1["forward"] - st0["forward"])
         out = {
             "metric": "env-steps/sec (whole node), RoboSumoAnts-v0 4096 envs, + PPO2 iters/sec",
@@ -193,13 +194,15 @@ def main():
                                    "(5 policy/value evaluations + env step of frame_skip 5 x RK4 + reward mix), random-init "
                                    "networks, auto-reset on" % (args.env_id, N),
                        "ppo2": ppo,
-                       "envs_per_gpu": N, "total_envs": N * world, "parallelism": "env-shard x%d" % world,
+                       "envs_per_gpu": N, "env_groups_per_gpu": env.groups, "total_envs": N * world, "parallelism": "env-shard x%d" % world,
                        "mean_contacts_per_forward": (st1["contacts"] - st0["contacts"]) / nfwd,
                        "mean_newton_iters_per_forward": (st1["newton"] - st0["newton"]) / nfwd,
                        "lds_bytes_per_env": env.engine.lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "sumo_step_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": B,
+                         "envs_per_launch": env.group_size, "concurrent_launches": env.groups,
+                         "aggregate_achieved": B * value / max(1, world) / 1e9,
                          "note": "latency/ALU-bound physics: ~20 forward-dynamics solves per 2.4 KB of state traffic"},
         }
         if states is not None:

@@ -51,6 +51,8 @@ class Runner(AbstractEnvRunner):
             raise ValueError("two-agent self-play only (runner.py assumes agents 0 and 1)")
         self.lam, self.gamma, self.rho_bar, self.c_bar = lam, gamma, rho_bar, c_bar
         self._side = None
+        self._gstreams = None
+        self._gsides = None
         self.recurrent = all(getattr(m, "recurrent", False) for m in models)
         self.device_mode = hasattr(env, "step_device") and (self.recurrent or all(
             hasattr(m, "act_model") and hasattr(m.act_model, "evaluate") for m in models))
@@ -107,61 +109,98 @@ class Runner(AbstractEnvRunner):
         return B
 
     def _step_device(self, B, s, alpha, env_events=None):
-        """One rollout step (runner.py:62-151): 4 fused policy launches (the reference's 5 evaluations), env step, reward mix."""
+        """One rollout step (runner.py:62-151): 4 fused policy launches (the reference's 5 evaluations), env step, reward mix.
+        With env groups (``SumoVecEnv(groups=G)``) every group runs this sequence on its own stream: a group's next step only
+        waits for that group's envs, not for the slowest env of the whole batch (``join_groups`` before reading the buffers)."""
         t = self._t
-        env, N = self.env, self.nenv
+        G = getattr(self.env, "groups", 1)
+        if G == 1:
+            self._step_group(B, s, alpha, None, slice(0, self.nenv), env_events)
+            return
+        if self._gstreams is None:
+            cur = t.cuda.current_stream(self.device)
+            self._gstreams = [t.cuda.Stream(device=self.device) for _ in range(G)]
+            self._gsides = [None] * G
+            for st in self._gstreams:
+                st.wait_stream(cur)
+        for g in range(G):
+            with t.cuda.stream(self._gstreams[g]):
+                self._step_group(B, s, alpha, g, self.env._gs(g), env_events if g == 0 else None)
+
+    def join_groups(self):
+        """Make the current stream wait for every env group's stream (no-op without groups)."""
+        if self._gstreams is not None:
+            cur = self._t.cuda.current_stream(self.device)
+            for st in self._gstreams:
+                cur.wait_stream(st)
+
+    def _step_group(self, B, s, alpha, g, sl, env_events):
+        t = self._t
+        env = self.env
+        n = sl.stop - sl.start
         learner, opp = self.models[0].act_model, self.models[1].act_model
-        PI, VF = ppo_capi.FWD_PI, ppo_capi.FWD_VF
-        ob = self.obs                                                    # [N, 2, D] view of the env's buffer
-        B["obs"][:, s].copy_(ob.permute(1, 0, 2))                        # one strided copy per array instead of one per agent
-        B["done"][:, s].copy_(self.dones.t())
-        o0, o1 = B["obs"][0, s], B["obs"][1, s]
+        ob, dn = env.obs_dev[sl], env.done_dev[sl]                      # [n, 2, D] / [n, 2]: the env's own buffers
+        B["obs"][:, s, sl].copy_(ob.permute(1, 0, 2))                   # one strided copy per array instead of one per agent
+        B["done"][:, s, sl].copy_(dn.t())
+        o0, o1 = B["obs"][0, s, sl], B["obs"][1, s, sl]
+        act0, act1 = B["act"][0, s, sl], B["act"][1, s, sl]
         if self.recurrent:
             # same five evaluations through the recurrent nets (runner.py:62-96 with the S / M feeds): each stream carries its
             # acting model's state; the scoring calls without a state feed start from zeros, as the reference's calls do
             m0, m1 = self.models
-            a0, v0, self.states[0], n0 = m0.step(o0, S=self.states[0], M=self.dones[:, 0])
-            B["act"][0, s].copy_(a0); B["val"][0, s].copy_(v0); B["nlp"][0, s].copy_(n0)
-            B["onlp"][0, s].copy_(m1.act_model.action_probability(o0, given_action=a0))
-            a1, _, self.states[1], on1 = m1.step(o1, S=self.states[1], M=self.dones[:, 1])
-            B["act"][1, s].copy_(a1); B["onlp"][1, s].copy_(on1)
-            B["val"][1, s].copy_(m0.value(o1, S=self.states[1], M=self.dones[:, 1]))
-            B["nlp"][1, s].copy_(m0.act_model.action_probability(o1, given_action=a1))
+            a0, v0, S0, n0 = m0.step(o0, S=self.states[0][sl], M=dn[:, 0])
+            self.states[0][sl] = S0
+            act0.copy_(a0); B["val"][0, s, sl].copy_(v0); B["nlp"][0, s, sl].copy_(n0)
+            B["onlp"][0, s, sl].copy_(m1.act_model.action_probability(o0, given_action=a0))
+            a1, _, S1, on1 = m1.step(o1, S=self.states[1][sl], M=dn[:, 1])
+            self.states[1][sl] = S1
+            act1.copy_(a1); B["onlp"][1, s, sl].copy_(on1)
+            B["val"][1, s, sl].copy_(m0.value(o1, S=S1, M=dn[:, 1]))
+            B["nlp"][1, s, sl].copy_(m0.act_model.action_probability(o1, given_action=a1))
         else:
-            self._policy_evals(B, s, learner, opp, o0, o1)
+            self._policy_evals(B, s, learner, opp, o0, o1, sl, g)
         act = env.act_dev
-        act.copy_(B["act"][:, s].permute(1, 0, 2))
+        act[sl].copy_(B["act"][:, s, sl].permute(1, 0, 2))
         if env_events is not None:
             env_events[0].record()
-        obs, info, done, er, edr, el = env.step_device(act)
+        if g is None:
+            env.step_device(act)
+        else:
+            env.step_device_group(g, act)
         if env_events is not None:
             env_events[1].record()
-        self.obs = obs
-        self.dones = done
         st = t.cuda.current_stream(self.device).cuda_stream
-        ppo_capi.chk(ppo_capi.lib().ppo_reward_mix(info.data_ptr(), N, alpha, B["rew"][0, s].data_ptr(), B["T"] * N, st))
-        B["ep_done"][s].copy_(done[:, 0])
-        B["ep_r"][s].copy_(er)
-        B["ep_l"][s].copy_(el)
+        ppo_capi.chk(ppo_capi.lib().ppo_reward_mix(env.info_dev[sl].data_ptr(), n, alpha, B["rew"][0, s, sl].data_ptr(),
+                                                   B["T"] * self.nenv, st))
+        B["ep_done"][s, sl].copy_(env.done_dev[sl][:, 0])
+        B["ep_r"][s, sl].copy_(env.ep_r_dev[sl])
+        B["ep_l"][s, sl].copy_(env.ep_l_dev[sl])
+        self.obs, self.dones = env.obs_dev, env.done_dev
 
-    def _policy_evals(self, B, s, learner, opp, o0, o1):
+    def _policy_evals(self, B, s, learner, opp, o0, o1, sl, g):
         """The two chains (learner acts on agent 0's stream and the opponent scores it; the opponent acts on agent 1's stream
         and the learner evaluates it) are independent: they run on two HIP streams and join before the env step."""
         t = self._t
         PI, VF = ppo_capi.FWD_PI, ppo_capi.FWD_VF
         cur = t.cuda.current_stream(self.device)
-        if self._side is None:
-            self._side = t.cuda.Stream(device=self.device)
-        side = self._side
+        if g is None:
+            if self._side is None:
+                self._side = t.cuda.Stream(device=self.device)
+            side = self._side
+        else:
+            if self._gsides[g] is None:
+                self._gsides[g] = t.cuda.Stream(device=self.device)
+            side = self._gsides[g]
         side.wait_stream(cur)
+        sa, sb = B["scratch_a"][sl], B["scratch_b"][sl]
         # agent 0 acts with the learner; the opponent net scores that action (runner.py:67-85)
-        learner.evaluate(o0, PI | VF, out=dict(action=B["act"][0, s], neglogp=B["nlp"][0, s], value=B["val"][0, s]))
-        opp.evaluate(o0, PI, given_action=B["act"][0, s], out=dict(neglogp=B["onlp"][0, s], action=B["scratch_a"]))
+        learner.evaluate(o0, PI | VF, out=dict(action=B["act"][0, s, sl], neglogp=B["nlp"][0, s, sl], value=B["val"][0, s, sl]))
+        opp.evaluate(o0, PI, given_action=B["act"][0, s, sl], out=dict(neglogp=B["onlp"][0, s, sl], action=sa))
         with t.cuda.stream(side):
             # agent 1 acts with the opponent; the learner net evaluates value and neglogp there (runner.py:86-96)
-            opp.evaluate(o1, PI, out=dict(action=B["act"][1, s], neglogp=B["onlp"][1, s]))
-            learner.evaluate(o1, PI | VF, given_action=B["act"][1, s],
-                             out=dict(neglogp=B["nlp"][1, s], value=B["val"][1, s], action=B["scratch_b"]))
+            opp.evaluate(o1, PI, out=dict(action=B["act"][1, s, sl], neglogp=B["onlp"][1, s, sl]))
+            learner.evaluate(o1, PI | VF, given_action=B["act"][1, s, sl],
+                             out=dict(neglogp=B["nlp"][1, s, sl], value=B["val"][1, s, sl], action=sb))
         cur.wait_stream(side)
 
     def _run_device(self, update):
@@ -170,8 +209,13 @@ class Runner(AbstractEnvRunner):
         B = self._alloc_device(T)
         alpha = anneal_alpha(update, self.anneal_bound)
         states0 = self.states[0].clone() if self.recurrent else None     # BPTT starts from the rollout's initial state
+        if self._gstreams is not None:                                   # the group streams see the parameter update that preceded this rollout
+            cur = t.cuda.current_stream(self.device)
+            for st in self._gstreams:
+                st.wait_stream(cur)
         for s in range(T):
             self._step_device(B, s, alpha)
+        self.join_groups()
         learner = self.models[0].act_model
         last_values = t.empty((2, N), dtype=t.float32, device=self.device)
         if self.recurrent:

@@ -63,14 +63,23 @@ class EnvSpec(object):
 
 
 class SumoVecEnv(VecEnv):
-    def __init__(self, env_id="RoboSumo-Ant-vs-Ant-v0", num_envs=1, seed=0, device=0, asset_dir=None, model=None):
+    def __init__(self, env_id="RoboSumo-Ant-vs-Ant-v0", num_envs=1, seed=0, device=0, asset_dir=None, model=None, groups=1):
+        """``groups`` > 1 splits the envs into that many equal, contiguous groups, each with its own engine: a group's step is
+        its own kernel launch (``step_device_group``), so a caller that advances the groups on separate streams is not held
+        back by the slowest env of the whole batch at every step (the device-mode Runner does that).  All buffers stay
+        unified ``[N, ...]`` tensors; ``step_device`` / the host API step every group."""
         import torch
         if not torch.cuda.is_available():
             raise capi.SumoHipError("SumoVecEnv needs a HIP device (there is no CPU fallback in the product path)")
         self._torch = torch
         self.model = model if model is not None else mjcf.load_model(env_id, asset_dir)
         self.device = torch.device("cuda", int(device))
-        self.engine = capi.Engine(self.model, num_envs, device=int(device))
+        groups = int(groups)
+        if groups < 1 or num_envs % groups:
+            raise ValueError("num_envs %d is not divisible into %d groups" % (num_envs, groups))
+        self.groups, self.group_size = groups, num_envs // groups
+        self.engines = [capi.Engine(self.model, self.group_size, device=int(device)) for _ in range(groups)]
+        self.engine = self.engines[0]                                   # dimensions / limits (identical for every group)
         E = self.engine
         obs_dims, act_dims = self.model.obs_dims, self.model.act_dims
         ob_spaces = [Box(-np.inf * np.ones(d), np.inf * np.ones(d)) for d in obs_dims]           # agents.py:85-90
@@ -102,11 +111,24 @@ class SumoVecEnv(VecEnv):
     def _stream(self):
         return self._torch.cuda.current_stream(self.device).cuda_stream
 
+    def _gs(self, g):
+        return slice(g * self.group_size, (g + 1) * self.group_size)
+
     def reset_device(self):
         self._assert_not_closed()
-        self.engine.reset(self.obs_dev.data_ptr(), seeds=self.seeds if self._needs_seed else None, stream=self._stream())
+        for g, E in enumerate(self.engines):
+            sl = self._gs(g)
+            E.reset(self.obs_dev[sl].data_ptr(), seeds=self.seeds[sl] if self._needs_seed else None, stream=self._stream())
         self._needs_seed = False
         return self.obs_dev
+
+    def step_device_group(self, g, actions):
+        """Advance group ``g`` only (its slice of every buffer), on the current stream.  ``actions`` is the FULL [N, 2, A]
+        action tensor; the group's rows are read."""
+        sl = self._gs(g)
+        self.engines[g].step(actions[sl].data_ptr(), self.obs_dev[sl].data_ptr(), self.info_dev[sl].data_ptr(),
+                             self.done_dev[sl].data_ptr(), self.ep_r_dev[sl].data_ptr(), self.ep_dr_dev[sl].data_ptr(),
+                             self.ep_l_dev[sl].data_ptr(), stream=self._stream())
 
     def step_device(self, actions):
         """actions: float32 CUDA tensor [N, 2, act_stride]. Returns (obs, info, done, ep_r, ep_dr, ep_l) tensors that
@@ -115,9 +137,21 @@ class SumoVecEnv(VecEnv):
         if actions.dtype != self._torch.float32 or not actions.is_cuda or not actions.is_contiguous() \
                 or tuple(actions.shape) != tuple(self.act_dev.shape):
             raise ValueError("actions must be a contiguous float32 CUDA tensor of shape %s" % (tuple(self.act_dev.shape),))
-        self.engine.step(actions.data_ptr(), self.obs_dev.data_ptr(), self.info_dev.data_ptr(), self.done_dev.data_ptr(),
-                         self.ep_r_dev.data_ptr(), self.ep_dr_dev.data_ptr(), self.ep_l_dev.data_ptr(), stream=self._stream())
+        for g in range(self.groups):
+            self.step_device_group(g, actions)
         return self.obs_dev, self.info_dev, self.done_dev, self.ep_r_dev, self.ep_dr_dev, self.ep_l_dev
+
+    def stats(self):
+        """Solver / contact statistics summed over the groups' engines (maxima for the ``max_*`` entries)."""
+        out = None
+        for E in self.engines:
+            st = E.stats()
+            if out is None:
+                out = dict(st)
+            else:
+                for k, v in st.items():
+                    out[k] = max(out[k], v) if k.startswith("max_") else out[k] + v
+        return out
 
     # ---- reference (host) API ------------------------------------------------------------------------------------
     def _obs_host(self):
@@ -177,7 +211,8 @@ class SumoVecEnv(VecEnv):
         return obs, rews, done, tuple(infos)
 
     def close_extras(self):
-        self.engine.close()
+        for E in self.engines:
+            E.close()
 
     def _assert_not_closed(self):
         assert not self.closed, "Trying to operate on a SumoVecEnv after calling close()"

@@ -279,3 +279,27 @@ def test_step_parity_when_agents_wrestle(env_id, tol):
     # (deep interpenetration can exceed the Jacobian pool: both sides drop the same contacts, in pair order)
     assert gst["dropped"] == ost["dropped"] and gst["max_ncon"] == ost["max_ncon"]
     assert two_body >= 12, two_body          # the scenario really exercises contacts between the agents
+
+
+def test_env_groups_are_transparent():
+    """SumoVecEnv(groups=G) steps G engines over slices of the same buffers: identical results to one engine, env by env."""
+    N, K = 64, 8
+    rng = np.random.default_rng(3)
+    acts = [torch.from_numpy(rng.standard_normal((N, 2, 8)).astype(np.float32)).cuda() for _ in range(K)]
+    outs = []
+    for G in (1, 4):
+        env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=N, seed=33, groups=G)
+        assert env.groups == G and env.group_size == N // G
+        rec = [env.reset_device().clone()]
+        for a in acts:
+            obs, info, done, ep_r, _, ep_l = env.step_device(a)
+            rec.append(torch.cat([obs.flatten(), info.flatten().float(), done.flatten().float(), ep_l.flatten().float()]).clone())
+        torch.cuda.synchronize()
+        st = env.stats()
+        outs.append((rec, st))
+        env.close()
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    assert outs[0][1]["forward"] == outs[1][1]["forward"] and outs[0][1]["newton"] == outs[1][1]["newton"]
+    with pytest.raises(ValueError):
+        SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=10, groups=4)

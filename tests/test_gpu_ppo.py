@@ -323,3 +323,31 @@ def test_graph_replay_matches_eager_steps():
     assert res[0][2] == res[1][2] == 6
     assert torch.equal(res[0][0], res[1][0])
     assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_grouped_rollout_and_update():
+    """Device-mode Runner over an env with groups: every group advances on its own stream; buffers, V-trace inputs and the
+    update stay consistent (finite, right shapes, per-env episode bookkeeping intact)."""
+    env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=64, seed=2, groups=4)
+    learner = _model(121, 8, seed=1)
+    opp = _model(121, 8, seed=2, trainable=False)
+    learner.act_model.seed(1); opp.act_model.seed(2)
+    r = Runner(env=env, models=[learner, opp], nsteps=24, nagent=2, gamma=0.995, lam=0.95, rho_bar=1.0, c_bar=1.0)
+    assert r.device_mode
+    for upd in (1, 2):
+        out = r.run(upd)
+        torch.cuda.synchronize()
+        obs, returns, masks, actions, values, nlp = out[0], out[1], out[2], out[3], out[4], out[5]
+        assert tuple(obs.shape) == (2, 64 * 24, 121) and tuple(actions.shape) == (2, 64 * 24, 8)
+        for x in (obs, returns, actions, values, nlp):
+            assert torch.isfinite(x).all()
+        # the time feature of every env advances by 2/500 per step within an episode (sumo_env.py:40-72): no env was skipped
+        tf = obs[0].reshape(64, 24, 121)[:, :, -1]
+        m0 = masks[0].reshape(64, 24)
+        d = tf[:, 1:] - tf[:, :-1]
+        same_ep = ~m0[:, 1:]
+        assert torch.allclose(d[same_ep], torch.full_like(d[same_ep], 2.0 / 500.0), atol=1e-6)
+        w = torch.ones(64 * 24, dtype=torch.float32, device=DEV)
+        st = learner.train_indexed(1e-3, 0.2, obs[0].contiguous(), returns[0], actions[0], values[0], nlp[0], w, None, 64 * 24)
+        assert np.isfinite(st[:5]).all()
+    env.close()
