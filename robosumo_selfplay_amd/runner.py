@@ -182,17 +182,20 @@ class Runner(AbstractEnvRunner):
         and the learner evaluates it) are independent: they run on two HIP streams and join before the env step."""
         t = self._t
         PI, VF = ppo_capi.FWD_PI, ppo_capi.FWD_VF
-        cur = t.cuda.current_stream(self.device)
-        if g is None:
-            if self._side is None:
-                self._side = t.cuda.Stream(device=self.device)
-            side = self._side
-        else:
-            if self._gsides[g] is None:
-                self._gsides[g] = t.cuda.Stream(device=self.device)
-            side = self._gsides[g]
-        side.wait_stream(cur)
         sa, sb = B["scratch_a"][sl], B["scratch_b"][sl]
+        if g is not None:
+            # env groups already overlap with each other; more streams than hardware queues (4 by default) only serialise
+            learner.evaluate(o0, PI | VF, out=dict(action=B["act"][0, s, sl], neglogp=B["nlp"][0, s, sl], value=B["val"][0, s, sl]))
+            opp.evaluate(o0, PI, given_action=B["act"][0, s, sl], out=dict(neglogp=B["onlp"][0, s, sl], action=sa))
+            opp.evaluate(o1, PI, out=dict(action=B["act"][1, s, sl], neglogp=B["onlp"][1, s, sl]))
+            learner.evaluate(o1, PI | VF, given_action=B["act"][1, s, sl],
+                             out=dict(neglogp=B["nlp"][1, s, sl], value=B["val"][1, s, sl], action=sb))
+            return
+        cur = t.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = t.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(cur)
         # agent 0 acts with the learner; the opponent net scores that action (runner.py:67-85)
         learner.evaluate(o0, PI | VF, out=dict(action=B["act"][0, s, sl], neglogp=B["nlp"][0, s, sl], value=B["val"][0, s, sl]))
         opp.evaluate(o0, PI, given_action=B["act"][0, s, sl], out=dict(neglogp=B["onlp"][0, s, sl], action=sa))
