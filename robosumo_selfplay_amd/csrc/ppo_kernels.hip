@@ -167,7 +167,7 @@ extern __shared__ float smem_f[];
 
 __global__ void __launch_bounds__(256) ppo_forward_kernel(FwdArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + wid, r0 = tile * 16;
+  const int tile = blockIdx.x * (blockDim.x >> 6) + wid, r0 = tile * 16;
   if (r0 >= a.n) return;
   const int XS = a.XS, D = a.L.D, A = a.L.A;
   float* base = smem_f + wid * (16 * XS + 2 * 16 * HS);
@@ -233,14 +233,17 @@ extern "C" int ppo_forward_filtered(const float* params, const float* obs, int n
   a.value = value_out; a.mean = mean_out; a.n = n; a.obs_stride = obs_stride; a.flags = flags; a.XS = x_stride(ob_dim);
   a.f_mean = obs_mean; a.f_invstd = obs_invstd; a.f_clip = obs_clip;
   a.L = make_layout(ob_dim, ac_dim);
-  size_t lds = (size_t)4 * (16 * a.XS + 2 * 16 * HS) * sizeof(float);
+  // one wave (one 16-row tile) per workgroup: 29 KB of LDS each, so a tile can start on any CU as soon as a little LDS frees
+  // up next to the env kernels of another env group (a 4-wave workgroup needed 116 KB at once)
+  const int wpb = 1;
+  size_t lds = (size_t)wpb * (16 * a.XS + 2 * 16 * HS) * sizeof(float);
   int tiles = (n + 15) / 16;
   static thread_local size_t lds_set = 0;   // raise the dynamic-LDS limit once (per thread / size), not on every launch
   if (lds > 64 * 1024 && lds > lds_set) {
     HIPCHK(hipFuncSetAttribute((const void*)ppo_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
-  hipLaunchKernelGGL(ppo_forward_kernel, dim3((tiles + 3) / 4), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ppo_forward_kernel, dim3((tiles + wpb - 1) / wpb), dim3(64 * wpb), lds, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
