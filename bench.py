@@ -147,27 +147,28 @@ def main():
     ppo = None
     if args.ppo_nsteps > 0:
         T, nmb, nep = args.ppo_nsteps, hp["nminibatches"], hp["noptepochs"]
-        barrier()
-        tu = time.perf_counter()
-        out = runner.run(1)
-        torch.cuda.synchronize(dev)
-        t_roll = time.perf_counter() - tu
-        obs_b, ret_b, act_b, val_b, nlp_b = out[0][0].contiguous(), out[1][0], out[3][0], out[4][0], out[5][0]
-        nb = N * T
-        wts = torch.ones(nb, dtype=torch.float32, device=dev)
-        for ep in range(nep):
-            inds = torch.from_numpy(np.random.permutation(nb).astype(np.int32)).to(dev)
-            for start in range(0, nb, nb // nmb):
-                mb = inds[start:start + nb // nmb]
-                learner.train_indexed(hp["lr"], hp["cliprange"], obs_b, ret_b, act_b, val_b, nlp_b, wts, mb, int(mb.numel()), sync=False)
-        barrier()
-        t_upd = time.perf_counter() - tu
-        tt = torch.tensor([t_upd, t_roll], dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ppo = {"iters_per_sec": 1.0 / float(tt[0].item()), "nsteps": T, "nminibatches": nmb, "noptepochs": nep,
-               "rollout_s": float(tt[1].item()), "sgd_s": float(tt[0].item() - tt[1].item()),
-               "samples_per_iter": nb * world}
+        for timed_update in (False, True):     # the first update pays one-time costs (graph capture, lazy initialisation): untimed
+            barrier()
+            tu = time.perf_counter()
+            out = runner.run(1)
+            torch.cuda.synchronize(dev)
+            t_roll = time.perf_counter() - tu
+            obs_b, ret_b, act_b, val_b, nlp_b = out[0][0].contiguous(), out[1][0], out[3][0], out[4][0], out[5][0]
+            nb = N * T
+            wts = torch.ones(nb, dtype=torch.float32, device=dev)
+            for ep in range(nep):
+                inds = torch.randperm(nb, device=dev).to(torch.int32)      # device-side shuffle (np.random.shuffle in alg_ppo.py:375)
+                for start in range(0, nb, nb // nmb):
+                    mb = inds[start:start + nb // nmb]
+                    learner.train_indexed(hp["lr"], hp["cliprange"], obs_b, ret_b, act_b, val_b, nlp_b, wts, mb, int(mb.numel()), sync=False)
+            barrier()
+            t_upd = time.perf_counter() - tu
+            tt = torch.tensor([t_upd, t_roll], dtype=torch.float64, device=dev)
+            if dist is not None:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ppo = {"iters_per_sec": 1.0 / float(tt[0].item()), "nsteps": T, "nminibatches": nmb, "noptepochs": nep,
+                   "rollout_s": float(tt[1].item()), "sgd_s": float(tt[0].item() - tt[1].item()),
+                   "samples_per_iter": nb * world}
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:

@@ -87,6 +87,8 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
     runner = Runner(env=env, models=models, nsteps=nsteps, nagent=nagent, gamma=gamma, lam=lam, rho_bar=rho_bar, c_bar=c_bar,
                     anneal_bound=anneal_bound)
     epinfobuf = deque(maxlen=100)
+    shuffle_gen = torch.Generator(device=dev)
+    shuffle_gen.manual_seed((seed or 0) * 7919 + 13)          # same minibatch order on every rank (equal shards)
     if init_fn is not None:
         init_fn()
     tfirststart = time.perf_counter()
@@ -198,7 +200,7 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
                                       b_nlp[mbflat], None, weights[mbflat], st0[torch.from_numpy(mbenv).to(dev)], nsteps=nsteps)
                     mblossvals.append(torch.tensor([float(x) for x in out[:5]], dtype=torch.float64))
         for epoch in range(noptepochs if not recurrent else 0):
-            inds = torch.from_numpy(np.random.permutation(nsamp).astype(np.int32)).to(dev)    # np.random.shuffle (:375)
+            inds = torch.randperm(nsamp, device=dev, generator=shuffle_gen).to(torch.int32)   # np.random.shuffle (:375), on the device
             for ii, start in enumerate(range(0, nsamp, nbatch_train)):
                 mb = inds[start:start + nbatch_train]
                 # statistics stay on the device unless the KL early stop needs them now (alg_ppo.py:389-398)

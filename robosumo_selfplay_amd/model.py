@@ -44,6 +44,7 @@ class PPOModel(object):
             self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
             self.workspace = torch.empty(ppo_capi.lib().ppo_grad_workspace_bytes(D, A), dtype=torch.uint8, device=self.device)
             self._graphs = {}
+            self._static = None
 
     # ---- checkpoints: list of 13 float32 arrays in TF variable order (model.py:153-177) -----------------------
     def get_param_list(self):
@@ -111,8 +112,20 @@ class PPOModel(object):
     def _graph_step(self, lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n):
         t = self._t
         A = self.spec.ac_dim
-        key = (obs.data_ptr(), obs.stride(0), returns.data_ptr(), actions.data_ptr(), values.data_ptr(), neglogpacs.data_ptr(),
-               weights.data_ptr(), int(n), float(cliprange))
+        # The batch arrays of an update are copied ONCE into buffers owned by the model (a device copy per update, not per
+        # step), so the captured graph keeps valid pointers across updates and is captured once per batch shape.
+        src = (obs.data_ptr(), returns.data_ptr(), actions.data_ptr(), values.data_ptr(), neglogpacs.data_ptr(), weights.data_ptr())
+        shp = (tuple(obs.shape), obs.stride(0))
+        if self._static is None or self._static["shape"] != shp:
+            self._static = dict(shape=shp, src=None, bufs=[t.empty_like(x, memory_format=t.contiguous_format)
+                                                           for x in (obs, returns, actions, values, neglogpacs, weights)])
+            self._graphs.clear()
+        if self._static["src"] != src:
+            for dst, x in zip(self._static["bufs"], (obs, returns, actions, values, neglogpacs, weights)):
+                dst.copy_(x)
+            self._static["src"] = src
+        obs, returns, actions, values, neglogpacs, weights = self._static["bufs"]
+        key = (int(n), float(cliprange))
         g = self._graphs.get(key)
         if g is None:
             if len(self._graphs) >= 2:
