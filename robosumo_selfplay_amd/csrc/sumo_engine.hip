@@ -1521,6 +1521,9 @@ __device__ __forceinline__ void newton_solve(C& c) {
     cost = solver_cost(c, Ma, xi);
   }
   int iters = 0;
+  // loop invariants of this lane's dof, kept in registers: its limit rows, smooth force and unconstrained acceleration
+  const LimRows lq = lim_rows(c);
+  const double qsm_i = lane < nv ? S(qsm)[lane] : 0.0, asmo_i = lane < nv ? S(asmo)[lane] : 0.0;
   PROF(11);
   for (int iter = 0; iter < maxiter; iter++) {
     iters++;
@@ -1547,7 +1550,6 @@ __device__ __forceinline__ void newton_solve(C& c) {
     SYNC();
     // ---- gradient: own limit rows (lane-local) + dof-major gather of J^T f over the contacts touching the dof
     double g = 0, dl = 0;
-    const LimRows lq = lim_rows(c);
     if (lane < nv) {
       double qc = 0;
       const double j0 = xi - lq.A0, j1 = -xi - lq.A1;
@@ -1561,7 +1563,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
         const double* cp = S(cp) + 3 * ci;
         qc += Jb[s] * cp[0] + Jb[ns + s] * cp[1] + Jb[2 * ns + s] * cp[2];
       }
-      g = Ma - S(qsm)[lane] - qc;
+      g = Ma - qsm_i - qc;
       if (!TREE) S(dlim)[lane] = dl;
     }
     double gn = wave_sum(g * g);
@@ -1645,7 +1647,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
     }
     rj[RPL] = xi - lq.A0; rjv[RPL] = sr; rD[RPL] = lq.D0;
     rj[RPL + 1] = -xi - lq.A1; rjv[RPL + 1] = -sr; rD[RPL + 1] = lq.D1;
-    double g1 = wave_sum(lane < nv ? sr * (Ma - S(qsm)[lane]) : 0.0);
+    double g1 = wave_sum(lane < nv ? sr * (Ma - qsm_i) : 0.0);
     double g2 = wave_sum(lane < nv ? sr * Mv : 0.0);
     double alpha = 0, lo = 0, hi = -1, d0 = 0;
     for (int ls = 0; ls < 50; ls++) {
@@ -1674,7 +1676,15 @@ __device__ __forceinline__ void newton_solve(C& c) {
     }
     SYNC();
     double oldcost = cost;
-    cost = solver_cost(c, Ma, xi);
+    {  // cost at the new point from the rows this lane already holds (same terms as solver_cost, no LDS round trip)
+      double v = lane < nv ? 0.5 * (Ma - qsm_i) * (xi - asmo_i) : 0.0;
+      const double j0 = xi - lq.A0, j1 = -xi - lq.A1;
+      if (j0 < 0) v += 0.5 * lq.D0 * j0 * j0;
+      if (j1 < 0) v += 0.5 * lq.D1 * j1 * j1;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) { const double jn = rj[q] + alpha * rjv[q]; if (jn < 0) v += 0.5 * rD[q] * jn * jn; }
+      cost = wave_sum(v);
+    }
     if (scale * (oldcost - cost) < tol) break;
   }
   c.st_newton += iters;
