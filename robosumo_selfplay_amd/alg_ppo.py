@@ -145,7 +145,6 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
             off_policy_ratio, off_env_ratio, total_ratio = runner.run(update)
         torch.cuda.synchronize(dev)
         t_roll = time.perf_counter() - tstart
-        T, N = nsteps, nenvs
         if isinstance(obs, np.ndarray):       # host-mode Runner (recurrent models): continue on the device like the MLP path
             up = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(dev)
             obs, returns, masks, actions, values, neglogpacs, rewards, opponent_neglogpacs = map(

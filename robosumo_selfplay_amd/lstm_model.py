@@ -216,7 +216,6 @@ class LstmPPOModel(object):
             self.grads[self.P:] = self.stats.to(t.float32)
             sdist.allreduce_fused(self.grads, self.comm)
             self.stats.copy_(self.grads[self.P:].to(t.float64))
-        A = self.spec.ac_dim
         entropy = float((self.views[5].double() + 0.5 * np.log(2.0 * np.pi * np.e)).sum().item())
         self.t += 1
         ppo_capi.chk(L.ppo_clip_adam(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.P, self.t,
