@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/sumo_ppo.h"
 
@@ -647,20 +648,38 @@ extern "C" int ppo_vtrace(const float* rewards, const float* values, const float
 // advantage normalisation (model.py:180-185)
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) ppo_adv_moments_kernel(const float* ret, const float* val, const int32_t* idx, int n, double* mom) {
-  __shared__ double s1[1024], s2[1024];
+  // one block (a fixed summation order); the gathers of a 4-element batch are all in flight before the first add
+  __shared__ double s1[16], s2[16];
   double a = 0, b = 0;
-  for (int k = threadIdx.x; k < n; k += 1024) {
-    int r = idx ? idx[k] : k;
-    double d = (double)(ret[r] - val[r]);  // float32 subtraction first, as numpy does
-    a += d; b += d * d;
+  for (int k0 = threadIdx.x; k0 < n; k0 += 4096) {
+    int r[4];
+    float x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int k = k0 + 1024 * u;
+      r[u] = k < n ? (idx ? idx[k] : k) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      x[u] = r[u] >= 0 ? ret[r[u]] : 0.f;
+      y[u] = r[u] >= 0 ? val[r[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      double d = (double)(x[u] - y[u]);  // float32 subtraction first, as numpy does
+      a += d; b += d * d;
+    }
   }
-  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s1[w] = a; s2[w] = b; }
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0, tb = 0;
+    for (int i = 0; i < 16; i++) { ta += s1[i]; tb += s2[i]; }
+    mom[0] = ta; mom[1] = tb; mom[2] = (double)n;
   }
-  if (threadIdx.x == 0) { mom[0] = s1[0]; mom[1] = s2[0]; mom[2] = (double)n; }
 }
 __global__ void ppo_adv_normalize_kernel(const float* ret, const float* val, const int32_t* idx, int n, const double* mom, float* out) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -980,7 +999,13 @@ extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, i
   a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.log_ratio = log_ratio_out; a.L = make_layout(ob_dim, ac_dim);
   int ntiles = (n + 15) / 16;
   int nblocks = (ntiles + 3) / 4;
-  if (nblocks > 256) nblocks = 256;
+  {  // 128 blocks (two 16-row tiles per wave at 16384 rows) halve the slab traffic of one tile per wave: 268 vs 317 us per SGD step
+    const char* nbc = getenv("PPO_GRAD_BLOCKS");
+    int cap = nbc ? atoi(nbc) : 128;
+    if (cap < 1) cap = 1;
+    if (cap > 256) cap = 256;   // the workspace is sized for 256 blocks (grad_nwaves)
+    if (nblocks > cap) nblocks = cap;
+  }
   a.nwaves = nblocks * 4;
   a.slabs = (float*)workspace;
   a.wstats = (double*)((char*)workspace + (size_t)2 * grad_nwaves() * a.L.P * sizeof(float));
@@ -1012,21 +1037,33 @@ extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// clip_by_global_norm + TF1 Adam (single block: P ~ 25k)
+// clip_by_global_norm + TF1 Adam.  Every block computes the global norm itself (same loads, same order -> the same
+// value in every block; P ~ 25k floats sit in L2) and then updates its own 1024 parameters.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) ppo_clip_adam_kernel(float* params, const float* grads, float* m, float* v, int P, float lr_t,
                                                              float beta1, float beta2, float eps, float max_norm, double* stats) {
-  __shared__ double red[1024];
+  __shared__ double red[16];
   double s = 0;
-  for (int k = threadIdx.x; k < P; k += 1024) { double g = grads[k]; s += g * g; }
-  red[threadIdx.x] = s;
+  for (int k0 = threadIdx.x; k0 < P; k0 += 8 * 1024) {
+    float g[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { int k = k0 + 1024 * u; g[u] = k < P ? grads[k] : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) s += (double)g[u] * (double)g[u];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  float norm = (float)sqrt(red[0]);
+  double tot = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) tot += red[i];
+  float norm = (float)sqrt(tot);
   float scale = 1.0f;
   if (max_norm > 0.0f) scale = max_norm / fmaxf(norm, max_norm);          // tf.clip_by_global_norm
-  if (threadIdx.x == 0 && stats) stats[7] = (double)norm;
-  for (int k = threadIdx.x; k < P; k += 1024) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && stats) stats[7] = (double)norm;
+  const int k = blockIdx.x * 1024 + threadIdx.x;
+  if (k < P) {
     float g = grads[k] * scale;
     float mk = beta1 * m[k] + (1.0f - beta1) * g;
     float vk = beta2 * v[k] + (1.0f - beta2) * g * g;
@@ -1038,7 +1075,7 @@ extern "C" int ppo_clip_adam(float* params, const float* grads, float* m, float*
                              double eps, double max_grad_norm, double* stats, void* stream) {
   if (!params || !grads || !m || !v || P <= 0 || t < 1) FAIL(-1, "bad arguments");
   double lr_t = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
-  hipLaunchKernelGGL(ppo_clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, params, grads, m, v, P, (float)lr_t, (float)beta1,
+  hipLaunchKernelGGL(ppo_clip_adam_kernel, dim3((P + 1023) / 1024), dim3(1024), 0, (hipStream_t)stream, params, grads, m, v, P, (float)lr_t, (float)beta1,
                      (float)beta2, (float)eps, (float)max_grad_norm, stats);
   HIPCHK(hipGetLastError());
   return 0;
