@@ -286,6 +286,21 @@ def test_learn_plumbing_config1(tmp_path):
     env.close()
 
 
+@pytest.mark.parametrize("env_id", ["RoboSumo-Spider-vs-Spider-v0", "RoboSumo-Bug-vs-Bug-v0"])
+def test_learn_other_matchups(env_id, tmp_path):
+    """BASELINE config 4 (Spider-vs-Spider: ob 209 / ac 16 -> the widest kernel instantiations) and the Bug pair
+    through the same learn() loop: device rollout, V-trace, two updates, finite losses, parameters moved."""
+    from robosumo_selfplay_amd import alg_ppo, defaults
+    env = SumoVecEnv(env_id, num_envs=16, seed=3)
+    kw = defaults.get_default_params(env_id)
+    kw.update(nsteps=16, nminibatches=4, noptepochs=2)
+    model = alg_ppo.learn(network="mlp", env=env, seed=3, total_timesteps=16 * 16 * 2, nagent=2, log_dir=str(tmp_path), verbose=False, **kw)
+    assert model.spec.ob_dim == env.observation_space[0].shape[0] and model.spec.ac_dim == env.action_space[0].shape[0]
+    assert len(model.history["lossvals"]) == 2 and all(np.isfinite(l).all() for l in model.history["lossvals"])
+    assert model.t == 2 * 2 * 4 and torch.isfinite(model.params).all()
+    env.close()
+
+
 def test_learn_opponent_modes_and_opponent_data(tmp_path):
     from robosumo_selfplay_amd import alg_ppo
     env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=16, seed=1)
