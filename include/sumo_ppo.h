@@ -103,6 +103,25 @@ int ppo_lstm_bwd_step(const ppo_lstm_net* net, int n, const float* dlatent_t, co
  * (agent-major, one time slice of the rollout buffer) = alpha*shaping + (1-alpha)*main evaluated in float64. */
 int ppo_reward_mix(const double* info, int n, double alpha, float* reward_out, int agent_stride, void* stream);
 
+/* ppo_reward_mix plus the step's episode records (agent 0's done flag, episode return and length as the monitor wrapper
+ * reports them, bench/monitor.py:63-78) copied into one time slice of the rollout buffers: one launch per rollout step.
+ * done uint8 [n][2]; ep_r float64 [n]; ep_l int32 [n]. */
+int ppo_post_step(const double* info, int n, double alpha, float* reward_out, int agent_stride, const uint8_t* done,
+                  const double* ep_r, const int32_t* ep_l, uint8_t* ep_done_out, double* ep_r_out, int32_t* ep_l_out, void* stream);
+
+/* The five policy/value evaluations of one self-play rollout step (runner.py:62-96) in one launch, relu MLP nets.
+ * obs: observation of env e, agent g at obs + e*env_stride + g*agent_stride (float32, ob_dim values); the learner acts on
+ * agent 0 and the opponent on agent 1 (action = mean + exp(logstd) * noise_g[e]), each action is scored by the other net,
+ * and the learner's value net is evaluated on both agents' observations.
+ * act_env float32 [n][2][ac_dim] receives both actions (the env's action buffer).
+ * out_f32[10] = { obs_out0, obs_out1 (float32 [n][ob_dim] copies of the inputs, may be NULL), act0, act1 ([n][ac_dim]),
+ *                 nlp0, nlp1 (learner's neglogp of the action on side g), onlp0, onlp1 (opponent's), val0, val1 ([n]) }.
+ * out_done (may be NULL) = { done_out0, done_out1 } uint8 [n] copies of done_in[e][g] (done_in uint8 [n][2], may be NULL).
+ * Outputs equal those of the corresponding four ppo_forward calls bit for bit. */
+int ppo_selfplay_forward(const float* learner_params, const float* opponent_params, const float* obs, int n, int env_stride,
+                         int agent_stride, int ob_dim, int ac_dim, const float* noise0, const float* noise1,
+                         const uint8_t* done_in, float* act_env, float* const* out_f32, uint8_t* const* out_done, void* stream);
+
 /* Buffers [2][T][N] float32 (agent, time, env); dones uint8 [2][T][N] = done flags BEFORE each step; last_dones uint8
  * [N][2]; last_values float32 [2][N].  Outputs returns float32 [2][T][N], ratios float32 [T][N]. */
 int ppo_vtrace(const float* rewards, const float* values, const float* neglogp, const float* opp_neglogp,

@@ -67,16 +67,30 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_AC
 __device__ __forceinline__ void stage_x(float* xbuf, int XS, const float* obs, int obs_stride, int D, const int32_t* idx, int r0,
                                         int n, int lane, const float* f_mean = nullptr, const float* f_invstd = nullptr,
                                         float f_clip = 0.0f) {
-  for (int e = lane; e < 16 * XS; e += WAVE) {
-    int r = e / XS, c = e - r * XS;
-    float v = 0.0f;
-    int row = r0 + r;
-    if (row < n && c < D) {
-      int src = idx ? idx[row] : row;
-      v = obs[(size_t)src * obs_stride + c];
-      if (f_mean) v = fminf(fmaxf((v - f_mean[c]) * f_invstd[c], -f_clip), f_clip);
+  // one column chunk of all 16 rows at a time: the 16 row loads are in flight together (no per-element division either)
+  for (int c0 = 0; c0 < XS; c0 += WAVE) {
+    const int c = c0 + lane;
+    const bool cok = c < D;
+    const float fm = (f_mean && cok) ? f_mean[c] : 0.0f, fi = (f_mean && cok) ? f_invstd[c] : 1.0f;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = r0 + r;
+      v[r] = 0.0f;
+      if (row < n && cok) {
+        const int src = idx ? idx[row] : row;
+        v[r] = obs[(size_t)src * obs_stride + c];
+      }
     }
-    xbuf[e] = v;
+    if (f_mean) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (r0 + r < n && cok) v[r] = fminf(fmaxf((v[r] - fm) * fi, -f_clip), f_clip);
+    }
+    if (c < XS) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) xbuf[r * XS + c] = v[r];
+    }
   }
 }
 
@@ -89,15 +103,24 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
   f32x4 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
-  for (int k0 = 0; k0 < Dp; k0 += 4) {
-    int k = k0 + kq;
-    float a = xbuf[i * XS + k];
-    bool ok = k < D;
+  // k-steps are issued eight at a time with all of their operand loads in flight first (32 weight loads per batch): the
+  // accumulation order is unchanged, but one memory round trip is exposed per batch instead of one per k-step
+  for (int k0 = 0; k0 < Dp; k0 += 32) {
+    float a[8], b[8][4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) {
-      float b = ok ? net.w0[k * H + ct * 16 + i] : 0.0f;
-      acc[ct] = MFMA(a, b, acc[ct]);
+    for (int u = 0; u < 8; u++) {
+      const int k = k0 + 4 * u + kq;
+      const bool ok = k < D;
+      a[u] = ok ? xbuf[i * XS + k] : 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) b[u][ct] = ok ? net.w0[k * H + ct * 16 + i] : 0.0f;
     }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (k0 + 4 * u < Dp) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a[u], b[u][ct], acc[ct]);
+      }
   }
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
@@ -107,11 +130,18 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
     acc[ct] = (f32x4){0, 0, 0, 0};
   }
   wave_sync();
-  for (int k0 = 0; k0 < H; k0 += 4) {
-    int k = k0 + kq;
-    float a = h1buf[i * HS + k];
+  {
+    float b[H / 4][4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a, net.w1[k * H + ct * 16 + i], acc[ct]);
+    for (int u = 0; u < H / 4; u++)
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) b[u][ct] = net.w1[(4 * u + kq) * H + ct * 16 + i];
+#pragma unroll
+    for (int u = 0; u < H / 4; u++) {
+      const float a = h1buf[i * HS + 4 * u + kq];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a, b[u][ct], acc[ct]);
+    }
   }
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
@@ -122,11 +152,12 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
   wave_sync();
   f32x4 out = (f32x4){0, 0, 0, 0};
   const bool col_ok = i < net.nout;
-  for (int k0 = 0; k0 < H; k0 += 4) {
-    int k = k0 + kq;
-    float a = h2buf[i * HS + k];
-    float b = col_ok ? net.w2[k * net.nout + i] : 0.0f;
-    out = MFMA(a, b, out);
+  {
+    float b[H / 4];
+#pragma unroll
+    for (int u = 0; u < H / 4; u++) b[u] = col_ok ? net.w2[(4 * u + kq) * net.nout + i] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < H / 4; u++) out = MFMA(h2buf[i * HS + 4 * u + kq], b[u], out);
   }
   float bias = col_ok ? net.b2[i] : 0.0f;
 #pragma unroll
@@ -245,6 +276,119 @@ extern "C" int ppo_forward_filtered(const float* params, const float* obs, int n
     lds_set = lds;
   }
   hipLaunchKernelGGL(ppo_forward_kernel, dim3((tiles + wpb - 1) / wpb), dim3(64 * wpb), lds, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The five evaluations of one self-play rollout step (runner.py:62-96) in ONE launch: workgroup (tile, side) stages 16
+// observations of agent `side` once and runs the acting net's policy trunk (sample + neglogp), the other net's policy
+// trunk (neglogp of that action) and the learner's value trunk on them.  Same device functions and the same order of
+// operations as ppo_forward_kernel: the outputs are bit-identical to the four separate launches.
+// ---------------------------------------------------------------------------------------------------------
+struct SelfplayArgs {
+  const float *learner, *opponent, *obs, *noise0, *noise1;
+  const uint8_t* done_in;
+  float *act_env, *obs_out0, *obs_out1, *act0, *act1, *nlp0, *nlp1, *onlp0, *onlp1, *val0, *val1;
+  uint8_t *done_out0, *done_out1;
+  int n, env_stride, agent_stride, XS;
+  ParamLayout L;
+};
+
+// Gaussian head on a policy tile (D layout): samples (noise != nullptr) or scores `act`; returns the row's neglogp in
+// the lanes with i == 0 via nlp[r]
+__device__ __forceinline__ void gauss_head(const float* params, const ParamLayout& L, const f32x4& mean, const float* noise, int r0, int n,
+                                           int lane, float (&act)[4], float (&nlp)[4]) {
+  const int i = lane & 15, kq = lane >> 4, A = L.A;
+  const bool col = i < A;
+  const float logstd = col ? params[L.logstd + i] : 0.0f;
+  const float std = expf(logstd);
+  const float sum_logstd = row16_sum(logstd);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = r0 + 4 * kq + r;
+    const bool ok = col && row < n;
+    const float m = mean[r];
+    if (noise) act[r] = ok ? m + std * noise[(size_t)row * A + i] : m;
+    const float z = ok ? (act[r] - m) / std : 0.0f;
+    const float ss = row16_sum(z * z);
+    nlp[r] = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
+  }
+}
+
+__global__ void __launch_bounds__(64) ppo_selfplay_kernel(SelfplayArgs a) {
+  const int lane = threadIdx.x, side = blockIdx.y, r0 = blockIdx.x * 16;
+  if (r0 >= a.n) return;
+  const int XS = a.XS, D = a.L.D, A = a.L.A;
+  float *xbuf = smem_f, *h1 = xbuf + 16 * XS, *h2 = h1 + 16 * HS;
+  const int i = lane & 15, kq = lane >> 4;
+  stage_x(xbuf, XS, a.obs + (size_t)side * a.agent_stride, a.env_stride, D, nullptr, r0, a.n, lane);
+  wave_sync();
+  const float* actor = side == 0 ? a.learner : a.opponent;
+  const float* scorer = side == 0 ? a.opponent : a.learner;
+  float act[4], nlp_actor[4], nlp_scorer[4];
+  {
+    f32x4 mean = trunk_forward<false>(pi_net(actor, a.L), xbuf, XS, D, h1, h2, lane);
+    gauss_head(actor, a.L, mean, side == 0 ? a.noise0 : a.noise1, r0, a.n, lane, act, nlp_actor);
+  }
+  wave_sync();
+  {
+    f32x4 mean = trunk_forward<false>(pi_net(scorer, a.L), xbuf, XS, D, h1, h2, lane);
+    gauss_head(scorer, a.L, mean, nullptr, r0, a.n, lane, act, nlp_scorer);
+  }
+  wave_sync();
+  const f32x4 v = trunk_forward<false>(vf_net(a.learner, a.L), xbuf, XS, D, h1, h2, lane);
+  float* act_out = side == 0 ? a.act0 : a.act1;
+  float* nlp_out = side == 0 ? a.nlp0 : a.nlp1;        // the LEARNER's neglogp of the action taken on this side
+  float* onlp_out = side == 0 ? a.onlp0 : a.onlp1;     // the OPPONENT's
+  float* val_out = side == 0 ? a.val0 : a.val1;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = r0 + 4 * kq + r;
+    if (row >= a.n) continue;
+    if (i < A) {
+      act_out[(size_t)row * A + i] = act[r];
+      a.act_env[((size_t)row * 2 + side) * A + i] = act[r];
+    }
+    if (i == 0) {
+      nlp_out[row] = side == 0 ? nlp_actor[r] : nlp_scorer[r];
+      onlp_out[row] = side == 0 ? nlp_scorer[r] : nlp_actor[r];
+      val_out[row] = v[r];
+    }
+  }
+  // rollout records of the inputs: the staged observations and the done flags the step started from
+  float* obs_out = side == 0 ? a.obs_out0 : a.obs_out1;
+  if (obs_out) {
+    for (int r = 0; r < 16 && r0 + r < a.n; r++)
+      for (int c = lane; c < D; c += WAVE) obs_out[(size_t)(r0 + r) * D + c] = xbuf[r * XS + c];
+  }
+  uint8_t* done_out = side == 0 ? a.done_out0 : a.done_out1;
+  if (done_out && a.done_in && lane < 16 && r0 + lane < a.n) done_out[r0 + lane] = a.done_in[(size_t)(r0 + lane) * 2 + side];
+}
+
+extern "C" int ppo_selfplay_forward(const float* learner_params, const float* opponent_params, const float* obs, int n, int env_stride,
+                                    int agent_stride, int ob_dim, int ac_dim, const float* noise0, const float* noise1,
+                                    const uint8_t* done_in, float* act_env, float* const* out_f32, uint8_t* const* out_done,
+                                    void* stream) {
+  if (!learner_params || !opponent_params || !obs || !noise0 || !noise1 || !act_env || !out_f32 || n <= 0) FAIL(-1, "bad arguments");
+  if (ac_dim < 1 || ac_dim > MAXA) FAIL(-2, "ac_dim %d not in [1,%d]", ac_dim, MAXA);
+  if (ob_dim < 1 || ob_dim > 512 || agent_stride < ob_dim || env_stride < agent_stride + ob_dim) FAIL(-3, "bad ob_dim / strides");
+  for (int k = 2; k < 10; k++) if (!out_f32[k]) FAIL(-4, "output %d missing", k);
+  SelfplayArgs a;
+  a.learner = learner_params; a.opponent = opponent_params; a.obs = obs; a.noise0 = noise0; a.noise1 = noise1; a.done_in = done_in;
+  a.act_env = act_env;
+  a.obs_out0 = out_f32[0]; a.obs_out1 = out_f32[1]; a.act0 = out_f32[2]; a.act1 = out_f32[3]; a.nlp0 = out_f32[4]; a.nlp1 = out_f32[5];
+  a.onlp0 = out_f32[6]; a.onlp1 = out_f32[7]; a.val0 = out_f32[8]; a.val1 = out_f32[9];
+  a.done_out0 = out_done ? out_done[0] : nullptr; a.done_out1 = out_done ? out_done[1] : nullptr;
+  a.n = n; a.env_stride = env_stride; a.agent_stride = agent_stride; a.XS = x_stride(ob_dim);
+  a.L = make_layout(ob_dim, ac_dim);
+  size_t lds = (size_t)(16 * a.XS + 2 * 16 * HS) * sizeof(float);
+  static thread_local size_t lds_set = 0;
+  if (lds > 64 * 1024 && lds > lds_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)ppo_selfplay_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(ppo_selfplay_kernel, dim3((n + 15) / 16, 2), dim3(64), lds, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -589,6 +733,25 @@ __global__ void ppo_reward_mix_kernel(const double* info, int n, double alpha, f
   const double* I = info + (size_t)(2 * e + g) * 8;
   out[(size_t)g * agent_stride + e] = (float)(alpha * I[6] + (1 - alpha) * I[3]);  // runner.py:134
 }
+// reward mix plus the episode records of the step (monitor.py:63-78 harvest): one launch instead of four
+__global__ void ppo_post_step_kernel(const double* info, int n, double alpha, float* out, int agent_stride, const uint8_t* done,
+                                     const double* ep_r, const int32_t* ep_l, uint8_t* ep_done_out, double* ep_r_out, int32_t* ep_l_out) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * n) return;
+  int e = t >> 1, g = t & 1;
+  const double* I = info + (size_t)(2 * e + g) * 8;
+  out[(size_t)g * agent_stride + e] = (float)(alpha * I[6] + (1 - alpha) * I[3]);  // runner.py:134
+  if (g == 0) { ep_done_out[e] = done[2 * e]; ep_r_out[e] = ep_r[e]; ep_l_out[e] = ep_l[e]; }
+}
+extern "C" int ppo_post_step(const double* info, int n, double alpha, float* reward_out, int agent_stride, const uint8_t* done,
+                             const double* ep_r, const int32_t* ep_l, uint8_t* ep_done_out, double* ep_r_out, int32_t* ep_l_out,
+                             void* stream) {
+  if (!info || !reward_out || !done || !ep_r || !ep_l || !ep_done_out || !ep_r_out || !ep_l_out || n <= 0) FAIL(-1, "bad arguments");
+  hipLaunchKernelGGL(ppo_post_step_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, info, n, alpha, reward_out,
+                     agent_stride, done, ep_r, ep_l, ep_done_out, ep_r_out, ep_l_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 extern "C" int ppo_reward_mix(const double* info, int n, double alpha, float* reward_out, int agent_stride, void* stream) {
   if (!info || !reward_out || n <= 0) FAIL(-1, "bad arguments");
   hipLaunchKernelGGL(ppo_reward_mix_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, info, n, alpha, reward_out,
@@ -746,11 +909,18 @@ __device__ __forceinline__ void backprop_hidden(const float* delta_in, const flo
   f32x4 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
-  for (int k0 = 0; k0 < H; k0 += 4) {
-    int k = k0 + kq;
-    float a = delta_in[i * HS + k];
+  {  // all 64 weight loads in flight before the first product (see trunk_forward)
+    float b[H / 4][4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a, W[(ct * 16 + i) * H + k], acc[ct]);
+    for (int u = 0; u < H / 4; u++)
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) b[u][ct] = W[(ct * 16 + i) * H + 4 * u + kq];
+#pragma unroll
+    for (int u = 0; u < H / 4; u++) {
+      const float a = delta_in[i * HS + 4 * u + kq];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a, b[u][ct], acc[ct]);
+    }
   }
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
@@ -858,13 +1028,21 @@ __device__ __forceinline__ void grad_net(const GradArgs& a, float* lds, int wave
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
       const int nk = (net.nout + 3) & ~3;
-      for (int k0 = 0; k0 < nk; k0 += 4) {
-        int k = k0 + kq;
-        float av = dout[i * 18 + k];
-        bool kok = k < net.nout;
+      float bw[4][4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(av, kok ? net.w2[(ct * 16 + i) * net.nout + k] : 0.0f, acc[ct]);
+      for (int u = 0; u < 4; u++) {
+        const int k = 4 * u + kq;
+        const bool kok = k < net.nout;
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) bw[u][ct] = kok ? net.w2[(ct * 16 + i) * net.nout + k] : 0.0f;
       }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (4 * u < nk) {
+          const float av = dout[i * 18 + 4 * u + kq];
+#pragma unroll
+          for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(av, bw[u][ct], acc[ct]);
+        }
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) {
         float s = 0;

@@ -2060,7 +2060,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   PROF(19);
   // work estimate for the next launch's longest-first schedule (sumo_step): Newton iterations dominate the variation
   // (a contention-independent proxy; sorting by the measured cycle count of the previous step schedules no better)
-  if (lane == 0 && a.cost) a.cost[e] = 1600 + 12 * c.st_newton + 2 * c.st_ncon + (dn ? 150 : 0);
+  if (lane == 0 && a.cost) { const int w = 1600 + 12 * c.st_newton + 2 * c.st_ncon + (dn ? 150 : 0); a.cost[e] = w < 65535 ? w : 65535; }
   flush_stats(c, a.stats);
 }
 
@@ -2100,6 +2100,30 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
     int* o = a.dbg_counts + 4 * e;
     o[0] = c.ncon; o[1] = c.nefc; o[2] = c.st_newton; o[3] = c.ndropped;
   }
+}
+
+// Longest-first schedule for small launches: perm[rank] = env, rank = number of envs with a larger (cost, -index) key --
+// the same order as a stable descending sort.  One-wave workgroups without LDS and with a handful of registers: they slip
+// into whatever slot an env wave of the other group's launch frees, where a library sort's large workgroups wait until that
+// whole launch has been placed (136 us on average between two env steps of a group, measured; this kernel: ~10 us).
+#define SCHED_RANK_MAX 4096
+__global__ void __launch_bounds__(WAVE) sched_rank_kernel(const int* __restrict__ cost, int n, int* __restrict__ perm) {
+  const int lane = threadIdx.x, e = blockIdx.x * WAVE + lane;
+  const int mine = e < n ? ((cost[e] << 12) | (SCHED_RANK_MAX - 1 - e)) : 0x7FFFFFFF;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 8 * WAVE) {   // 512 keys per batch: eight coalesced loads in flight, then lane broadcasts
+    int key[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = j0 + WAVE * u + lane;
+      key[u] = j < n ? ((cost[j] << 12) | (SCHED_RANK_MAX - 1 - j)) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int l = 0; l < WAVE; l++) rank += (__builtin_amdgcn_readlane(key[u], l) > mine) ? 1 : 0;
+  }
+  if (e < n) perm[rank] = e;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2733,8 +2757,13 @@ extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_d
   SUMO_DISPATCH(sumo_step_kernel, E, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
   if (E->sched) {
-    HIPCHK(rocprim::radix_sort_pairs_desc(E->d_sort_tmp, E->sort_tmp_bytes, E->d_cost, E->d_cost_sorted, E->d_iota, E->d_perm,
-                                          (size_t)E->N, 0, 16, (hipStream_t)stream));
+    if (E->N <= SCHED_RANK_MAX) {   // costs stay below 2^16 (see the step kernel's epilogue), so the packed key fits an int
+      hipLaunchKernelGGL(sched_rank_kernel, dim3((E->N + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, E->d_cost, E->N, E->d_perm);
+      HIPCHK(hipGetLastError());
+    } else {
+      HIPCHK(rocprim::radix_sort_pairs_desc(E->d_sort_tmp, E->sort_tmp_bytes, E->d_cost, E->d_cost_sorted, E->d_iota, E->d_perm,
+                                            (size_t)E->N, 0, 16, (hipStream_t)stream));
+    }
     E->perm_valid = true;
   }
   return 0;

@@ -140,11 +140,17 @@ class Runner(AbstractEnvRunner):
         n = sl.stop - sl.start
         learner, opp = self.models[0].act_model, self.models[1].act_model
         ob, dn = env.obs_dev[sl], env.done_dev[sl]                      # [n, 2, D] / [n, 2]: the env's own buffers
-        B["obs"][:, s, sl].copy_(ob.permute(1, 0, 2))                   # one strided copy per array instead of one per agent
-        B["done"][:, s, sl].copy_(dn.t())
+        fused = self._fused_ok(learner, opp)
+        if fused:
+            self._selfplay_forward(B, s, learner, opp, ob, dn, sl)      # records obs / dones, evaluates, fills env.act_dev
+        else:
+            B["obs"][:, s, sl].copy_(ob.permute(1, 0, 2))               # one strided copy per array instead of one per agent
+            B["done"][:, s, sl].copy_(dn.t())
         o0, o1 = B["obs"][0, s, sl], B["obs"][1, s, sl]
         act0, act1 = B["act"][0, s, sl], B["act"][1, s, sl]
-        if self.recurrent:
+        if fused:
+            pass
+        elif self.recurrent:
             # same five evaluations through the recurrent nets (runner.py:62-96 with the S / M feeds): each stream carries its
             # acting model's state; the scoring calls without a state feed start from zeros, as the reference's calls do
             m0, m1 = self.models
@@ -160,7 +166,8 @@ class Runner(AbstractEnvRunner):
         else:
             self._policy_evals(B, s, learner, opp, o0, o1, sl, g)
         act = env.act_dev
-        act[sl].copy_(B["act"][:, s, sl].permute(1, 0, 2))
+        if not fused:
+            act[sl].copy_(B["act"][:, s, sl].permute(1, 0, 2))
         if env_events is not None:
             env_events[0].record()
         if g is None:
@@ -170,12 +177,39 @@ class Runner(AbstractEnvRunner):
         if env_events is not None:
             env_events[1].record()
         st = t.cuda.current_stream(self.device).cuda_stream
-        ppo_capi.chk(ppo_capi.lib().ppo_reward_mix(env.info_dev[sl].data_ptr(), n, alpha, B["rew"][0, s, sl].data_ptr(),
-                                                   B["T"] * self.nenv, st))
-        B["ep_done"][s, sl].copy_(env.done_dev[sl][:, 0])
-        B["ep_r"][s, sl].copy_(env.ep_r_dev[sl])
-        B["ep_l"][s, sl].copy_(env.ep_l_dev[sl])
+        # reward mix (runner.py:134) + the step's episode records, one launch
+        ppo_capi.chk(ppo_capi.lib().ppo_post_step(env.info_dev[sl].data_ptr(), n, alpha, B["rew"][0, s, sl].data_ptr(), B["T"] * self.nenv,
+                                                  env.done_dev[sl].data_ptr(), env.ep_r_dev[sl].data_ptr(), env.ep_l_dev[sl].data_ptr(),
+                                                  B["ep_done"][s, sl].data_ptr(), B["ep_r"][s, sl].data_ptr(),
+                                                  B["ep_l"][s, sl].data_ptr(), st))
         self.obs, self.dones = env.obs_dev, env.done_dev
+
+    def _fused_ok(self, learner, opp):
+        """One-launch evaluation (``ppo_selfplay_forward``) applies when both sides are plain MLP policies of the same shape."""
+        from .policies import PolicyWithValue
+        env = self.env
+        return (not self.recurrent and type(learner) is PolicyWithValue and type(opp) is PolicyWithValue
+                and learner.spec.ob_dim == opp.spec.ob_dim == self.ob_dim and learner.spec.ac_dim == opp.spec.ac_dim
+                and env.act_dev.shape[2] == learner.spec.ac_dim and env.obs_dev.stride(2) == 1)
+
+    def _selfplay_forward(self, B, s, learner, opp, ob, dn, sl):
+        """runner.py:62-96 in one launch: learner acts on agent 0 (opponent scores it), opponent acts on agent 1 (learner scores
+        it and evaluates the value); the kernel also records the observations / done flags and writes the env's action buffer.
+        Noise comes from each acting model's own generator, as in ``PolicyWithValue.evaluate``."""
+        import ctypes as C
+        t = self._t
+        n = sl.stop - sl.start
+        D, A = learner.spec.ob_dim, learner.spec.ac_dim
+        noise0 = t.randn((n, A), generator=learner.gen, device=self.device, dtype=t.float32)
+        noise1 = t.randn((n, A), generator=opp.gen, device=self.device, dtype=t.float32)
+        outs = [B["obs"][0, s, sl], B["obs"][1, s, sl], B["act"][0, s, sl], B["act"][1, s, sl], B["nlp"][0, s, sl], B["nlp"][1, s, sl],
+                B["onlp"][0, s, sl], B["onlp"][1, s, sl], B["val"][0, s, sl], B["val"][1, s, sl]]
+        fp = (C.c_void_p * 10)(*[x.data_ptr() for x in outs])
+        dp = (C.c_void_p * 2)(B["done"][0, s, sl].data_ptr(), B["done"][1, s, sl].data_ptr())
+        ppo_capi.chk(ppo_capi.lib().ppo_selfplay_forward(learner.params.data_ptr(), opp.params.data_ptr(), ob.data_ptr(), n, ob.stride(0),
+                                                         ob.stride(1), D, A, noise0.data_ptr(), noise1.data_ptr(), dn.data_ptr(),
+                                                         self.env.act_dev[sl].data_ptr(), fp, dp,
+                                                         t.cuda.current_stream(self.device).cuda_stream))
 
     def _policy_evals(self, B, s, learner, opp, o0, o1, sl, g):
         """The two chains (learner acts on agent 0's stream and the opponent scores it; the opponent acts on agent 1's stream

@@ -340,6 +340,49 @@ def test_graph_replay_matches_eager_steps():
     assert np.array_equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("ob,ac,n", [(121, 8, 100), (209, 16, 37)])
+def test_selfplay_forward_equals_separate_evaluations(ob, ac, n):
+    """ppo_selfplay_forward (one launch per rollout step) against the four ppo_forward launches it replaces: bit-identical
+    actions, neglogps and values; observation / done records copied; env action buffer filled."""
+    import ctypes as C
+    from robosumo_selfplay_amd import ppo_capi
+    learner, opp = _model(ob, ac, seed=1).act_model, _model(ob, ac, seed=2, trainable=False).act_model
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    stride = ob + 3
+    obs = torch.randn((n, 2, stride), generator=g, device=DEV)
+    noise = torch.randn((2, n, ac), generator=g, device=DEV)
+    done = (torch.rand((n, 2), generator=g, device=DEV) < 0.3).to(torch.uint8)
+    PI, VF = ppo_capi.FWD_PI, ppo_capi.FWD_VF
+    L = ppo_capi.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    ref = {}
+    for side, actor, scorer in ((0, learner, opp), (1, opp, learner)):
+        o = obs[:, side, :]
+        a = torch.empty((n, ac), device=DEV); nl_a = torch.empty(n, device=DEV); nl_s = torch.empty(n, device=DEV); v = torch.empty(n, device=DEV)
+        ppo_capi.chk(L.ppo_forward(actor.params.data_ptr(), o.data_ptr(), n, o.stride(0), ob, ac, PI, noise[side].data_ptr(), None,
+                                   a.data_ptr(), nl_a.data_ptr(), None, None, st))
+        ppo_capi.chk(L.ppo_forward(scorer.params.data_ptr(), o.data_ptr(), n, o.stride(0), ob, ac, PI, None, a.data_ptr(),
+                                   None, nl_s.data_ptr(), None, None, st))
+        ppo_capi.chk(L.ppo_forward(learner.params.data_ptr(), o.data_ptr(), n, o.stride(0), ob, ac, VF, None, None, None, None,
+                                   v.data_ptr(), None, st))
+        ref[side] = dict(act=a, nlp=nl_a if side == 0 else nl_s, onlp=nl_s if side == 0 else nl_a, val=v)
+    outs = [torch.empty((n, ob), device=DEV), torch.empty((n, ob), device=DEV), torch.empty((n, ac), device=DEV), torch.empty((n, ac), device=DEV)]
+    outs += [torch.empty(n, device=DEV) for _ in range(6)]
+    douts = [torch.empty(n, dtype=torch.uint8, device=DEV) for _ in range(2)]
+    act_env = torch.zeros((n, 2, ac), device=DEV)
+    fp = (C.c_void_p * 10)(*[x.data_ptr() for x in outs])
+    dp = (C.c_void_p * 2)(*[x.data_ptr() for x in douts])
+    ppo_capi.chk(L.ppo_selfplay_forward(learner.params.data_ptr(), opp.params.data_ptr(), obs.data_ptr(), n, obs.stride(0), obs.stride(1),
+                                        ob, ac, noise[0].data_ptr(), noise[1].data_ptr(), done.data_ptr(), act_env.data_ptr(), fp, dp, st))
+    torch.cuda.synchronize()
+    for side in (0, 1):
+        assert torch.equal(outs[side], obs[:, side, :ob])
+        assert torch.equal(outs[2 + side], ref[side]["act"]) and torch.equal(act_env[:, side], ref[side]["act"])
+        assert torch.equal(outs[4 + side], ref[side]["nlp"]) and torch.equal(outs[6 + side], ref[side]["onlp"])
+        assert torch.equal(outs[8 + side], ref[side]["val"])
+        assert torch.equal(douts[side], done[:, side])
+
+
 def test_grouped_rollout_and_update():
     """Device-mode Runner over an env with groups: every group advances on its own stream; buffers, V-trace inputs and the
     update stay consistent (finite, right shapes, per-env episode bookkeeping intact)."""
