@@ -60,6 +60,11 @@ int sumo_stats(sumo_handle_t h, double* out8);
  * -DSUMO_PROFILE (HOST float64 [24]). */
 int sumo_profile(sumo_handle_t h, double* out24);
 
+/* development: from the next sumo_step on, every env wave stores {start stamp, end stamp (100 MHz s_memrealtime),
+ * Newton iterations | contacts << 32, dense-solver forwards | constraint rows << 32} of its step in stamps_dev (DEVICE
+ * uint64 [E][4]); NULL switches the trace off.  Used by tools/slot_trace.py. */
+int sumo_debug_trace(sumo_handle_t h, uint64_t* stamps_dev);
+
 #ifdef __cplusplus
 }
 #endif

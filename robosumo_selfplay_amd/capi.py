@@ -39,6 +39,8 @@ def lib():
         L.sumo_debug_forward.argtypes = [vp] * 4
         L.sumo_stats.argtypes = [vp, vp]
         L.sumo_profile.argtypes = [vp, vp]
+        L.sumo_debug_trace.argtypes = [vp, vp]
+        L.sumo_debug_trace.restype = i32
         L.sumo_profile.restype = i32
         for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_get_state",
                   "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
@@ -48,7 +50,7 @@ def lib():
 
 
 EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step",
-           "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile")
+           "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace")
 
 
 def _np(a):
@@ -126,6 +128,10 @@ class Engine:
         counts = np.zeros((self.N, 4), np.int32)
         _chk(lib().sumo_debug_forward(self.h, _np(ctrl), _np(qacc), _np(counts)))
         return qacc, counts
+
+    def debug_trace(self, stamps_ptr):
+        """Development: device uint64 [N][4] buffer that receives each env wave's start / end stamps and work counters (0 / None = off)."""
+        _chk(lib().sumo_debug_trace(self.h, stamps_ptr or None))
 
     def profile(self):
         o = np.zeros(24)

@@ -67,6 +67,7 @@ struct Layout {  // LDS offsets in doubles unless noted
   int jbcap;     // capacity of the contact-Jacobian pool in 24-double halves (3 rows x 8 slots); a contact between two
                  // moving bodies takes two halves, a contact with the world one
   int tree_ok;    // the dof tree has the shape tree_factor_solve assumes (checked in build_layout)
+  int force_dense;  // development (SUMO_FORCE_DENSE_H=1): Newton Hessians always through the general dense path
   int warm_mode;  // 0: MuJoCo semantics (solver starts from qacc_warmstart of the previous mj_step); 1: RK stages 2-4 start
                   // from the previous stage's solution (same optimum within the solver tolerance, fewer Newton iterations)
   int qpos, qvel, warm, ctrl, x0, accv, acca, tmpv;
@@ -102,6 +103,10 @@ struct StepArgs {
   const uint8_t* mask;  // reset only
   const int* perm;      // step: workgroup b advances env perm[b] (NULL = identity); see sumo_step
   int* cost;            // step: per-env work estimate written for the next launch's schedule
+  const int* rank_cost; // step: the first rank_blocks workgroups rank these estimates (of the previous launch) into
+  int* rank_perm;       //       the schedule of the NEXT launch instead of advancing an env (sched_rank)
+  int rank_blocks;
+  unsigned long long* trace;   // development: [N][4] wall-clock (100 MHz) stamps of each env wave's start / end, work counters (sumo_debug_trace)
   unsigned long long* stats;
   int obs_stride, act_stride;
   int N;
@@ -411,7 +416,8 @@ struct Ctx {
   unsigned long long prof[24];   // 20 phases + 4 ad-hoc probe slots (PROBE(k))
 #endif
   // statistics accumulated over the launch
-  int st_forward, st_newton, st_ncon, st_nefc, st_maxcon, st_maxefc, st_maxnewton, st_dropped;
+  int st_forward, st_newton, st_ncon, st_nefc, st_maxcon, st_maxefc, st_maxnewton, st_dropped, st_dense, st_cross;
+  int hcross;
 };
 
 #define S(off) (c.sm + c.L.off)
@@ -1105,12 +1111,14 @@ __device__ __forceinline__ void make_constraint(C& c) {
   c.nlim = nlim;
   c.nefc = nlim + 4 * ncon;
   {
-    int two = 0;
+    int two = 0, cross = 0;
+    const int b1 = MI(agent_bodyadr)[1];
     for (int ci = lane; ci < ncon; ci += WAVE) {
       const int* cb = c.si + c.L.con_b + 4 * ci;
-      if (cb[0] != 0 && cb[1] != 0) two = 1;
+      if (cb[0] != 0 && cb[1] != 0) { two = 1; if ((cb[0] >= b1) != (cb[1] >= b1)) cross = 1; }
     }
-    c.htree = c.L.tree_ok && __ballot(two) == 0ull;
+    c.htree = c.L.tree_ok && !c.L.force_dense && __ballot(two) == 0ull;
+    c.hcross = __ballot(cross) != 0ull;
   }
   // contact row parameters (same for the 4 pyramid edges of a contact)
   for (int ci = lane; ci < ncon; ci += WAVE) {
@@ -1582,9 +1590,9 @@ __device__ __forceinline__ void newton_solve(C& c) {
       int pi[C::EPL], pj[C::EPL];   // chain positions of the entry's two dofs (slot lookup, SLOT_OF)
 #pragma unroll
       for (int m = 0; m < C::EPL; m++) {
-        ent[m] = c.ent[m]; asm volatile("" : "+v"(ent[m]));
-        const unsigned e = ent[m] == 0xFFFFu ? 0u : ent[m];
-        pi[m] = c.P->lanes[e >> 8].d_pos; pj[m] = c.P->lanes[e & 0xFF].d_pos;
+        unsigned w = c.ent[m]; asm volatile("" : "+v"(w));
+        ent[m] = w & 0xFFFFu;
+        pi[m] = (w >> 16) & 0xF; pj[m] = (w >> 20) & 0xF;
       }
 #pragma unroll
       for (int m = 0; m < C::EPL; m++) {
@@ -1731,6 +1739,7 @@ __device__ __forceinline__ void forward(C& c) {
     for (int m = 0; m < C::EPL; m++) {
       unsigned e = c.ent[m];
       asm volatile("" : "+v"(e));   // keep the address arithmetic of this rarely taken block out of the kernel prologue
+      e &= 0xFFFFu;
       if (e != 0xFFFFu) { int i = e >> 8, jj = e & 0xFF; S(H)[HP(i, jj)] = SAME_TREE(i, jj) ? S(M)[MIDX(i, jj)] : 0.0; }
     }
     SYNC();
@@ -1740,7 +1749,16 @@ __device__ __forceinline__ void forward(C& c) {
   if (lane < nv) S(asmo)[lane] = as;
   SYNC();
   PROF(10);
-  if (c.htree) newton_solve<true>(c); else newton_solve<false>(c);
+  if (c.htree) newton_solve<true>(c);
+  else {
+    // The general (dense-factorisation) path costs ~1.65x a tree-path forward and the envs on it -- agents in contact with each
+    // other, a few per launch -- are the stragglers every launch waits for (tools/slot_trace.py).  From its first dense
+    // forward on, such a wave issues ahead of the wave it shares the SIMD with (which has slack).
+    if (c.st_dense == 0) __builtin_amdgcn_s_setprio(3);
+    newton_solve<false>(c);
+    c.st_dense++;
+    if (c.hcross) c.st_cross++;
+  }
   PROF(16);
   c.st_ncon += c.ncon;
   c.st_nefc += c.nefc;
@@ -1910,7 +1928,12 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
 #pragma unroll
   for (int m = 0; m < C::EPL; m++) {
     int t = c.lane + WAVE * m;
-    c.ent[m] = t < P->aux.ntri ? (unsigned)((P->aux.ai[P->aux.o_tri_i + t] << 8) | P->aux.ai[P->aux.o_tri_j + t]) : 0xFFFFu;
+    unsigned w = 0xFFFFu;
+    if (t < P->aux.ntri) {   // bits 16..19 / 20..23: chain positions of the two dofs (slot lookup in the dense Hessian assembly)
+      const int i = P->aux.ai[P->aux.o_tri_i + t], j = P->aux.ai[P->aux.o_tri_j + t];
+      w = (unsigned)((i << 8) | j) | ((unsigned)P->lanes[i].d_pos << 16) | ((unsigned)P->lanes[j].d_pos << 20);
+    }
+    c.ent[m] = w;
   }
   c.kp = P->lanes + c.lane;
   c.prp = P->pair_rec + c.lane;
@@ -1929,7 +1952,7 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.dpos = P->lanes[c.lane].d_pos;
   __syncthreads();
   c.ncon = c.nlim = c.nefc = c.ndropped = c.use_prev = 0;
-  c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = 0;
+  c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = c.st_dense = c.st_cross = 0;
 #ifdef SUMO_PROFILE
   for (int k = 0; k < 24; k++) c.prof[k] = 0;
   c.tprev = clock64();
@@ -1971,6 +1994,31 @@ __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
 // ---------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------
+// Longest-first schedule for small launches: perm[rank] = env, rank = number of envs with a larger (cost, -index) key --
+// the same order as a stable descending sort.  Run by the first workgroups of the step launch itself (on the estimates
+// of the PREVIOUS launch, for the NEXT one), so no kernel sits between two env steps of a group for it: a library sort
+// there cost 136 us on average (its large workgroups wait until the other group's whole launch has been placed), a
+// separate rank kernel still 35-40 us.
+#define SCHED_RANK_MAX 4096
+__device__ __forceinline__ void sched_rank(const int* __restrict__ cost, int n, int* __restrict__ perm, int block, int lane) {
+  const int e = block * WAVE + lane;
+  const int mine = e < n ? ((cost[e] << 12) | (SCHED_RANK_MAX - 1 - e)) : 0x7FFFFFFF;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 8 * WAVE) {   // 512 keys per batch: eight coalesced loads in flight, then lane broadcasts
+    int key[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = j0 + WAVE * u + lane;
+      key[u] = j < n ? ((cost[j] << 12) | (SCHED_RANK_MAX - 1 - j)) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll 8
+      for (int l = 0; l < WAVE; l++) rank += (__builtin_amdgcn_readlane(key[u], l) > mine) ? 1 : 0;
+  }
+  if (e < n) perm[rank] = e;
+}
+
 extern __shared__ double smem_dyn[];
 
 template <int NV>
@@ -1979,8 +2027,12 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   ctx_init(c, P, smem_dyn);
   const sumo_model_t& mdl = P->mdl;
   const int lane = c.lane;
-  if ((int)blockIdx.x >= a.N) return;
-  const int e = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;
+  if ((int)blockIdx.x < a.rank_blocks) { sched_rank(a.rank_cost, a.N, a.rank_perm, blockIdx.x, lane); return; }
+  const int bid = (int)blockIdx.x - a.rank_blocks;
+  if (bid >= a.N) return;
+  const int e = a.perm ? a.perm[bid] : bid;
+  if (a.perm && bid < (a.N >> 3)) __builtin_amdgcn_s_setprio(1);   // predicted-longest eighth of the launch: issue ahead of the SIMD mate
+  if (a.trace && lane == 0) a.trace[4 * e] = wall_clock64();
   load_state(c, a, e);
   if (lane < mdl.nu) {
     const float* act0 = a.actions + (size_t)e * 2 * a.act_stride;
@@ -2060,8 +2112,14 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   PROF(19);
   // work estimate for the next launch's longest-first schedule (sumo_step): Newton iterations dominate the variation
   // (a contention-independent proxy; sorting by the measured cycle count of the previous step schedules no better)
-  if (lane == 0 && a.cost) { const int w = 1600 + 12 * c.st_newton + 2 * c.st_ncon + (dn ? 150 : 0); a.cost[e] = w < 65535 ? w : 65535; }
+  // (least-squares fit of measured wave times, tools/slot_trace.py: Newton iterations, contacts, dense-path forwards)
+  if (lane == 0 && a.cost) { const int w = 1000 + 12 * c.st_newton + 10 * c.st_ncon + 60 * c.st_dense; a.cost[e] = w < 65535 ? w : 65535; }
   flush_stats(c, a.stats);
+  if (a.trace && lane == 0) {
+    a.trace[4 * e + 1] = wall_clock64();
+    a.trace[4 * e + 2] = (unsigned long long)c.st_newton | ((unsigned long long)c.st_ncon << 32);
+    a.trace[4 * e + 3] = (unsigned long long)c.st_dense | ((unsigned long long)c.st_cross << 16) | ((unsigned long long)c.st_nefc << 32);
+  }
 }
 
 template <int NV>
@@ -2102,30 +2160,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   }
 }
 
-// Longest-first schedule for small launches: perm[rank] = env, rank = number of envs with a larger (cost, -index) key --
-// the same order as a stable descending sort.  One-wave workgroups without LDS and with a handful of registers: they slip
-// into whatever slot an env wave of the other group's launch frees, where a library sort's large workgroups wait until that
-// whole launch has been placed (136 us on average between two env steps of a group, measured; this kernel: ~10 us).
-#define SCHED_RANK_MAX 4096
-__global__ void __launch_bounds__(WAVE) sched_rank_kernel(const int* __restrict__ cost, int n, int* __restrict__ perm) {
-  const int lane = threadIdx.x, e = blockIdx.x * WAVE + lane;
-  const int mine = e < n ? ((cost[e] << 12) | (SCHED_RANK_MAX - 1 - e)) : 0x7FFFFFFF;
-  int rank = 0;
-  for (int j0 = 0; j0 < n; j0 += 8 * WAVE) {   // 512 keys per batch: eight coalesced loads in flight, then lane broadcasts
-    int key[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int j = j0 + WAVE * u + lane;
-      key[u] = j < n ? ((cost[j] << 12) | (SCHED_RANK_MAX - 1 - j)) : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-#pragma unroll
-      for (int l = 0; l < WAVE; l++) rank += (__builtin_amdgcn_readlane(key[u], l) > mine) ? 1 : 0;
-  }
-  if (e < n) perm[rank] = e;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -2162,7 +2196,9 @@ struct sumo_engine {
   uint64_t* d_seeds = nullptr;
   unsigned long long* d_stats = nullptr;
   // longest-first scheduling of the env steps (see sumo_step)
-  int *d_cost = nullptr, *d_cost_sorted = nullptr, *d_iota = nullptr, *d_perm = nullptr;
+  int *d_cost = nullptr, *d_cost_sorted = nullptr, *d_iota = nullptr, *d_perm = nullptr;   // d_cost / d_perm: two buffers of N each
+  unsigned long long* d_trace = nullptr;   // sumo_debug_trace
+  long long sched_t = 0;                                                                     // step launches so far (in-kernel ranking)
   void* d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   bool sched = true, perm_valid = false;
@@ -2505,6 +2541,7 @@ static void build_layout(sumo_engine* E) {
   { int cap = 16 * (nv <= 36 ? 2 : 3); if (L.maxcon > cap) L.maxcon = cap; }  // contact rows per lane held in registers by the line search (newton_solve RPL)
   L.maxefc = 4 * L.maxcon + 2 * nhinge;
   { const char* wm = getenv("SUMO_WARM_MODE"); L.warm_mode = wm ? atoi(wm) : 0; }
+  { const char* fd = getenv("SUMO_FORCE_DENSE_H"); L.force_dense = fd ? atoi(fd) : 0; }
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
   L.qpos = take(nq); L.qvel = take(nv); L.warm = take(nv); L.ctrl = take(nu);
@@ -2650,10 +2687,10 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
   {
     const char* sc = getenv("SUMO_SCHED");
     E->sched = !(sc && atoi(sc) == 0);
-    HIPCHK(hipMalloc((void**)&E->d_cost, N * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&E->d_cost, 2 * N * sizeof(int)));
     HIPCHK(hipMalloc((void**)&E->d_cost_sorted, N * sizeof(int)));
     HIPCHK(hipMalloc((void**)&E->d_iota, N * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&E->d_perm, N * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&E->d_perm, 2 * N * sizeof(int)));
     std::vector<int> iota(N);
     for (size_t i = 0; i < N; i++) iota[i] = (int)i;
     HIPCHK(hipMemcpy(E->d_iota, iota.data(), N * sizeof(int), hipMemcpyHostToDevice));
@@ -2709,9 +2746,10 @@ static bool for_kernel_variant(int nv, F&& f) {
 #undef X
   return false;
 }
-#define SUMO_DISPATCH(KERNEL, E, stream, args)                                                              \
+#define SUMO_DISPATCH(KERNEL, E, stream, args) SUMO_DISPATCH_N(KERNEL, E, stream, args, (E)->N)
+#define SUMO_DISPATCH_N(KERNEL, E, stream, args, nblocks)                                                   \
   do {                                                                                                       \
-    dim3 g_((E)->N), b_(WAVE);                                                                               \
+    dim3 g_(nblocks), b_(WAVE);                                                                              \
     size_t lds_ = (size_t)(E)->L.total_bytes;                                                                \
     if (!for_kernel_variant((E)->hm.nv, [&](auto nvc_) {                                                     \
           hipLaunchKernelGGL(KERNEL<decltype(nvc_)::value>, g_, b_, lds_, stream, (E)->d_params, args);      \
@@ -2753,19 +2791,36 @@ extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_d
   // Env steps differ in cost (Newton iterations, contacts) by up to ~1.6x and a launch is only N / (6 * 256) rounds deep, so
   // the slowest workgroups of the last round set the launch time.  Workgroups are dispatched in index order: hand the
   // envs out longest-first, using the work each env reported in its previous step (results do not depend on the order).
-  if (E->sched) { a.cost = E->d_cost; a.perm = E->perm_valid ? E->d_perm : nullptr; }
-  SUMO_DISPATCH(sumo_step_kernel, E, (hipStream_t)stream, a);
-  HIPCHK(hipGetLastError());
-  if (E->sched) {
-    if (E->N <= SCHED_RANK_MAX) {   // costs stay below 2^16 (see the step kernel's epilogue), so the packed key fits an int
-      hipLaunchKernelGGL(sched_rank_kernel, dim3((E->N + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, E->d_cost, E->N, E->d_perm);
-      HIPCHK(hipGetLastError());
-    } else {
-      HIPCHK(rocprim::radix_sort_pairs_desc(E->d_sort_tmp, E->sort_tmp_bytes, E->d_cost, E->d_cost_sorted, E->d_iota, E->d_perm,
-                                            (size_t)E->N, 0, 16, (hipStream_t)stream));
+  a.trace = E->d_trace;
+  int nblocks = E->N;
+  if (E->sched && E->N <= SCHED_RANK_MAX) {
+    // in-kernel ranking (sched_rank): launch t writes its estimates to cost[t & 1]; its first workgroups rank cost[(t-1) & 1]
+    // into perm[(t+1) & 1]; it is itself scheduled by perm[t & 1], ranked during launch t-1 from the estimates of launch t-2
+    const long long t = E->sched_t++;
+    a.cost = E->d_cost + (size_t)(t & 1) * E->N;
+    a.perm = t >= 2 ? E->d_perm + (size_t)(t & 1) * E->N : nullptr;
+    if (t >= 1) {
+      a.rank_cost = E->d_cost + (size_t)((t - 1) & 1) * E->N;
+      a.rank_perm = E->d_perm + (size_t)((t + 1) & 1) * E->N;
+      a.rank_blocks = (E->N + WAVE - 1) / WAVE;
+      nblocks += a.rank_blocks;
     }
+  } else if (E->sched) {
+    a.cost = E->d_cost; a.perm = E->perm_valid ? E->d_perm : nullptr;
+  }
+  SUMO_DISPATCH_N(sumo_step_kernel, E, (hipStream_t)stream, a, nblocks);
+  HIPCHK(hipGetLastError());
+  if (E->sched && E->N > SCHED_RANK_MAX) {   // costs stay below 2^16 (see the step kernel's epilogue)
+    HIPCHK(rocprim::radix_sort_pairs_desc(E->d_sort_tmp, E->sort_tmp_bytes, E->d_cost, E->d_cost_sorted, E->d_iota, E->d_perm,
+                                          (size_t)E->N, 0, 16, (hipStream_t)stream));
     E->perm_valid = true;
   }
+  return 0;
+}
+
+extern "C" int sumo_debug_trace(sumo_handle_t E, uint64_t* stamps_dev) {
+  if (!E) FAIL(-1, "bad handle");
+  E->d_trace = (unsigned long long*)stamps_dev;
   return 0;
 }
 
