@@ -181,7 +181,7 @@ def main():
         B = algorithmic_bytes_per_env_step(model)
         traffic = None
         try:   # PMC traffic is collected offline with rocprofv3 (profiles/README.md); reported only for the profiled config
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")))   # newest collection
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")))   # newest collection
             if ("<%d>" % model.nv) in pj["kernel"] and pj["envs"] == env.group_size:
                 traffic = pj["traffic_bytes_per_launch"]
         except Exception:

@@ -25,7 +25,14 @@ def per_launch(path, kernel_sub="sumo_step_kernel", skip=5):
 if sys.argv[1] == "traffic":
     name, grid, f = per_launch(sys.argv[2]); _, _, w = per_launch(sys.argv[3])
     fk, nf = f["FETCH_SIZE"]; wk, nw = w["WRITE_SIZE"]
-    res = {"kernel": name, "envs": grid // 64, "launches_averaged": [nf, nw],
+    wgs = grid // 64
+    # launches of <= 4096 envs carry ceil(N / 64) extra workgroups that rank the next launch's schedule (sumo_step): N + ceil(N/64) = wgs
+    envs = wgs
+    for n in range(wgs, 0, -1):
+        if n <= 4096 and n + (n + 63) // 64 == wgs:
+            envs = n
+            break
+    res = {"kernel": name, "envs": envs, "workgroups": wgs, "launches_averaged": [nf, nw],
            "FETCH_SIZE_kb_per_launch": fk, "WRITE_SIZE_kb_per_launch": wk,
            "fetch_bytes_corrected_x2": fk * 1024 * 2, "write_bytes": wk * 1024,
            "traffic_bytes_per_launch": fk * 1024 * 2 + wk * 1024,
