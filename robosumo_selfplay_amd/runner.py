@@ -59,6 +59,12 @@ class Runner(AbstractEnvRunner):
         self.device = getattr(env, "device", None) or device or torch.device("cuda", 0)
         ob_shape = env.observation_space[0].shape
         self.ob_dim = ob_shape[0]
+        if len(env.observation_space) > 1 and (env.observation_space[1].shape != ob_shape or
+                                               env.action_space[1].shape != env.action_space[0].shape):
+            # the reference sizes its buffers and both policies from observation_space[0] as well (runner.py:14-16)
+            raise ValueError("self-play rollouts need both agents to share observation and action spaces; mixed match-ups "
+                             "(%s vs %s) run in the env engine and the evaluator only"
+                             % (ob_shape, env.observation_space[1].shape))
         if self.device_mode:
             self.obs = env.reset_device()                               # [N, 2, D] float32, stays in HBM
             self.dones = torch.zeros((self.nenv, 2), dtype=torch.uint8, device=self.device)

@@ -383,6 +383,14 @@ def test_selfplay_forward_equals_separate_evaluations(ob, ac, n):
         assert torch.equal(douts[side], done[:, side])
 
 
+def test_runner_rejects_mixed_matchups():
+    env = SumoVecEnv("RoboSumo-Ant-vs-Bug-v0", num_envs=4, seed=0)
+    with pytest.raises(ValueError, match="share observation and action spaces"):
+        Runner(env=env, models=[_model(121, 8, seed=1), _model(121, 8, seed=2, trainable=False)], nsteps=4, nagent=2, gamma=0.99,
+               lam=0.95, rho_bar=1.0, c_bar=1.0)
+    env.close()
+
+
 def test_grouped_rollout_and_update():
     """Device-mode Runner over an env with groups: every group advances on its own stream; buffers, V-trace inputs and the
     update stay consistent (finite, right shapes, per-env episode bookkeeping intact)."""
