@@ -66,9 +66,10 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_AC
 // (optional observation filter of the policy-zoo nets: clip((x - mean) * invstd, -clip, clip))
 __device__ __forceinline__ void stage_x(float* xbuf, int XS, const float* obs, int obs_stride, int D, const int32_t* idx, int r0,
                                         int n, int lane, const float* f_mean = nullptr, const float* f_invstd = nullptr,
-                                        float f_clip = 0.0f) {
-  // one column chunk of all 16 rows at a time: the 16 row loads are in flight together (no per-element division either)
-  for (int c0 = 0; c0 < XS; c0 += WAVE) {
+                                        float f_clip = 0.0f, int nthreads = WAVE) {
+  // one column chunk of all 16 rows at a time: the 16 row loads are in flight together (no per-element division either);
+  // `lane` may be a workgroup-wide thread id with nthreads = the workgroup size
+  for (int c0 = 0; c0 < XS; c0 += nthreads) {
     const int c = c0 + lane;
     const bool cok = c < D;
     const float fm = (f_mean && cok) ? f_mean[c] : 0.0f, fi = (f_mean && cok) ? f_invstd[c] : 1.0f;
@@ -394,8 +395,8 @@ extern "C" int ppo_selfplay_forward(const float* learner_params, const float* op
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// recurrent policies: one LSTM time step (see sumo_ppo.h).  One wave per 16-row tile, one wave per workgroup.
-// LDS per wave: x [16][XS] | emb [16][HS] | h_prev [16][HP] | h_new [16][HP]
+// recurrent policies: one LSTM time step (see sumo_ppo.h).  One workgroup of four waves per 16-row tile (a wave per
+// quarter of the units).  LDS per workgroup: x [16][XS] | emb [16][HS] | h_prev [16][HP] | h_new [16][HP]
 // ---------------------------------------------------------------------------------------------------------
 #define LSTM_MAXH 128
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -409,8 +410,11 @@ struct LstmArgs {
 };
 
 template <int NH, int ORDER>   // hidden units: 64 or 128; gate order (static so the gate tiles are static registers)
-__global__ void __launch_bounds__(64) ppo_lstm_step_kernel(LstmArgs a) {
-  const int lane = threadIdx.x, r0 = blockIdx.x * 16;
+__global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
+  // FOUR waves per 16-row tile: wave w owns the units [w NH/4, (w+1) NH/4) -- all four gates of those units, their cell
+  // update and their slice of the new latent -- so the serial chain per wave is a quarter of the tile's (one wave per tile
+  // took 150 us for H = 128 whatever the batch: 63 dependent k-steps of 32 products, then 128 units of transcendentals).
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r0 = blockIdx.x * 16;
   const ppo_lstm_net& N = a.net;
   const int D = N.ob_dim, E = N.emb_dim, A = N.ac_dim, XS = a.XS, HP = a.HP;
   float* xbuf = smem_f;
@@ -418,69 +422,103 @@ __global__ void __launch_bounds__(64) ppo_lstm_step_kernel(LstmArgs a) {
   float* hprev = ebuf + 16 * HS;
   float* hnew = hprev + 16 * HP;
   const int i = lane & 15, kq = lane >> 4;
-  stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, lane, N.obs_mean, N.obs_invstd, N.obs_clip);
-  for (int e = lane; e < 16 * NH; e += WAVE) {   // h_prev * (1 - mask)
-    int r = e / NH, k = e - r * NH, row = r0 + r;
-    float v = 0.0f;
-    if (row < a.n) { v = a.h[(size_t)row * a.state_stride + k]; if (a.mask) v *= 1.0f - a.mask[row]; }
-    hprev[r * HP + k] = v;
-    if (a.sv_hprev && row < a.n) a.sv_hprev[(size_t)row * NH + k] = v;
+  stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, tid, N.obs_mean, N.obs_invstd, N.obs_clip, 256);
+  // h_prev * (1 - mask): eight state loads in flight per thread
+  for (int e0 = 0; e0 < 16 * NH; e0 += 8 * 256) {
+    float v[8], keep[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + 256 * u + tid, r = e / NH, k = e - r * NH, row = r0 + r;
+      const bool in = e < 16 * NH && row < a.n;
+      v[u] = in ? a.h[(size_t)row * a.state_stride + k] : 0.0f;
+      keep[u] = (a.mask && in) ? 1.0f - a.mask[row] : 1.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + 256 * u + tid, r = e / NH, k = e - r * NH, row = r0 + r;
+      if (e < 16 * NH) {
+        const float hv = a.mask ? v[u] * keep[u] : v[u];
+        hprev[r * HP + k] = hv;
+        if (a.sv_hprev && row < a.n) a.sv_hprev[(size_t)row * NH + k] = hv;
+      }
+    }
   }
-  wave_sync();
-  // ---- optional embedding: relu(x * We + be), 64 wide
+  __syncthreads();
+  // ---- optional embedding: relu(x * We + be), 64 wide (wave 0)
   const float* xin = xbuf; int xk = D, xs = XS;
   if (N.emb_w) {
-    f32x4 acc[4];
+    if (wid == 0) {
+      f32x4 acc[4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
-    const int Dp = (D + 3) & ~3;
-    for (int k0 = 0; k0 < Dp; k0 += 4) {
-      int k = k0 + kq;
-      float av = xbuf[i * XS + k];
-      bool ok = k < D;
+      for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
+      const int Dp = (D + 3) & ~3;
+      for (int k0 = 0; k0 < Dp; k0 += 4) {
+        int k = k0 + kq;
+        float av = xbuf[i * XS + k];
+        bool ok = k < D;
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) { float b = (ok && ct * 16 + i < E) ? N.emb_w[k * E + ct * 16 + i] : 0.0f; acc[ct] = MFMA(av, b, acc[ct]); }
+        for (int ct = 0; ct < 4; ct++) { float b = (ok && ct * 16 + i < E) ? N.emb_w[k * E + ct * 16 + i] : 0.0f; acc[ct] = MFMA(av, b, acc[ct]); }
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) {
+        float bias = ct * 16 + i < E ? N.emb_b[ct * 16 + i] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) ebuf[(4 * kq + r) * HS + ct * 16 + i] = fmaxf(acc[ct][r] + bias, 0.0f);
+      }
     }
-#pragma unroll
-    for (int ct = 0; ct < 4; ct++) {
-      float bias = ct * 16 + i < E ? N.emb_b[ct * 16 + i] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 4; r++) ebuf[(4 * kq + r) * HS + ct * 16 + i] = fmaxf(acc[ct][r] + bias, 0.0f);
-    }
-    wave_sync();
+    __syncthreads();
     xin = ebuf; xk = E; xs = HS;
   }
-  // ---- gates z = x * wx + h_prev * wh + b : 4*NH columns = NH/4 tiles of 16
-  constexpr int NT = NH / 4;
-  f32x4 z[NT];
+  // ---- gates z = x * wx + h_prev * wh + b for this wave's units: tiles (gate g, unit tile wid*UTW + u)
+  constexpr int UT = NH / 16, UTW = UT / 4, NTW = 4 * UTW;   // unit tiles, unit tiles per wave, gate tiles per wave
+  f32x4 z[NTW];
 #pragma unroll
-  for (int ct = 0; ct < NT; ct++) z[ct] = (f32x4){0, 0, 0, 0};
+  for (int ct = 0; ct < NTW; ct++) z[ct] = (f32x4){0, 0, 0, 0};
   {
-    const int xp = (xk + 3) & ~3;
-    for (int k0 = 0; k0 < xp; k0 += 4) {
-      int k = k0 + kq;
-      float av = xin[i * xs + k];
-      bool ok = k < xk;
-      const float* wrow = N.wx + (size_t)(ok ? k : 0) * 4 * NH;
+    // k-steps run over the input block (wx) and then the recurrent block (wh); the weight operands of step s+1 are
+    // loaded before the products of step s are issued (two register sets); accumulation order per tile as ever
+    const int xsteps = (xk + 3) >> 2, nsteps = xsteps + NH / 4;
+    auto fetch = [&](int s_, float& av, float (&b)[NTW]) {
+      if (s_ < xsteps) {
+        const int k = 4 * s_ + kq;
+        const bool ok = k < xk;
+        av = ok ? xin[i * xs + k] : 0.0f;
+        const float* wrow = N.wx + (size_t)(ok ? k : 0) * 4 * NH;
 #pragma unroll
-      for (int ct = 0; ct < NT; ct++) z[ct] = MFMA(av, ok ? wrow[ct * 16 + i] : 0.0f, z[ct]);
-    }
-    for (int k0 = 0; k0 < NH; k0 += 4) {
-      int k = k0 + kq;
-      float av = hprev[i * HP + k];
-      const float* wrow = N.wh + (size_t)k * 4 * NH;
+        for (int g = 0; g < 4; g++)
 #pragma unroll
-      for (int ct = 0; ct < NT; ct++) z[ct] = MFMA(av, wrow[ct * 16 + i], z[ct]);
+          for (int u = 0; u < UTW; u++) b[g * UTW + u] = ok ? wrow[(g * UT + wid * UTW + u) * 16 + i] : 0.0f;
+      } else {
+        const int k = 4 * (s_ - xsteps) + kq;
+        av = hprev[i * HP + k];
+        const float* wrow = N.wh + (size_t)k * 4 * NH;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int u = 0; u < UTW; u++) b[g * UTW + u] = wrow[(g * UT + wid * UTW + u) * 16 + i];
+      }
+    };
+    float a0 = 0.0f, a1 = 0.0f, b0[NTW], b1[NTW];
+    fetch(0, a0, b0);
+    for (int s_ = 0; s_ < nsteps; s_ += 2) {
+      if (s_ + 1 < nsteps) fetch(s_ + 1, a1, b1);
+#pragma unroll
+      for (int ct = 0; ct < NTW; ct++) z[ct] = MFMA(a0, b0[ct], z[ct]);
+      if (s_ + 2 < nsteps) fetch(s_ + 2, a0, b0);
+      if (s_ + 1 < nsteps) {
+#pragma unroll
+        for (int ct = 0; ct < NTW; ct++) z[ct] = MFMA(a1, b1[ct], z[ct]);
+      }
     }
   }
   // ---- cell update.  Lane (i, kq) holds rows 4kq+r of columns ct*16+i: all four gates of unit j = ut*16+i
   constexpr int gi = 0, gf = ORDER == PPO_LSTM_GATES_IFOU ? 1 : 2, go = ORDER == PPO_LSTM_GATES_IFOU ? 2 : 3,
                 gu = ORDER == PPO_LSTM_GATES_IFOU ? 3 : 1;
-  constexpr int UT = NH / 16;   // unit tiles
 #pragma unroll
-  for (int ut = 0; ut < UT; ut++) {
+  for (int u = 0; u < UTW; u++) {
+    const int ut = wid * UTW + u;
     const int j = ut * 16 + i;
-    const f32x4 zi = z[gi * UT + ut], zf = z[gf * UT + ut], zo = z[go * UT + ut], zu = z[gu * UT + ut];
+    const f32x4 zi = z[gi * UTW + u], zf = z[gf * UTW + u], zo = z[go * UTW + u], zu = z[gu * UTW + u];
     const float bi = N.b[gi * NH + j], bf = N.b[gf * NH + j] + N.forget_bias, bo = N.b[go * NH + j], bu = N.b[gu * NH + j];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -500,12 +538,18 @@ __global__ void __launch_bounds__(64) ppo_lstm_step_kernel(LstmArgs a) {
       hnew[(4 * kq + r) * HP + j] = hn;
     }
   }
-  wave_sync();
-  // ---- heads on the new latent
-  if (N.head_w) {
+  __syncthreads();
+  // ---- heads on the new latent: wave 0 the Gaussian head, wave 1 the value head
+  if (wid == 0 && N.head_w && (a.action || a.neglogp || a.mean)) {   // (the training forward records the latents only)
     f32x4 m4 = (f32x4){0, 0, 0, 0};
     const bool col = i < A;
-    for (int k0 = 0; k0 < NH; k0 += 4) { int k = k0 + kq; m4 = MFMA(hnew[i * HP + k], col ? N.head_w[k * A + i] : 0.0f, m4); }
+    {
+      float hw[NH / 4];   // all head-weight operands in flight before the first product
+#pragma unroll
+      for (int u = 0; u < NH / 4; u++) hw[u] = col ? N.head_w[(4 * u + kq) * A + i] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < NH / 4; u++) m4 = MFMA(hnew[i * HP + 4 * u + kq], hw[u], m4);
+    }
     const float hb = col ? N.head_b[i] : 0.0f, logstd = col ? N.logstd[i] : 0.0f, std = expf(logstd);
     const float sum_logstd = row16_sum(logstd);
 #pragma unroll
@@ -525,9 +569,15 @@ __global__ void __launch_bounds__(64) ppo_lstm_step_kernel(LstmArgs a) {
       if (a.neglogp && i == 0 && row < a.n) a.neglogp[row] = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
     }
   }
-  if (N.vf_w && a.value) {
+  if (wid == 1 && N.vf_w && a.value) {
     f32x4 v4 = (f32x4){0, 0, 0, 0};
-    for (int k0 = 0; k0 < NH; k0 += 4) { int k = k0 + kq; v4 = MFMA(hnew[i * HP + k], i == 0 ? N.vf_w[k] : 0.0f, v4); }
+    {
+      float vw[NH / 4];
+#pragma unroll
+      for (int u = 0; u < NH / 4; u++) vw[u] = i == 0 ? N.vf_w[4 * u + kq] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < NH / 4; u++) v4 = MFMA(hnew[i * HP + 4 * u + kq], vw[u], v4);
+    }
     if (i == 0) {
 #pragma unroll
       for (int r = 0; r < 4; r++) { int row = r0 + 4 * kq + r; if (row < a.n) a.value[row] = v4[r] + N.vf_b[0]; }
@@ -556,7 +606,7 @@ static int lstm_launch(const ppo_lstm_net* net, const float* obs, int n, int obs
   int tiles = (n + 15) / 16;
   if (net->gate_order != PPO_LSTM_GATES_IFOU && net->gate_order != PPO_LSTM_GATES_IJFO) FAIL(-9, "unknown gate order %d", net->gate_order);
   const bool ifou = net->gate_order == PPO_LSTM_GATES_IFOU;
-  dim3 g(tiles), b(64);
+  dim3 g(tiles), b(256);
   hipStream_t st = (hipStream_t)stream;
   if (net->hidden == 64 && ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IFOU>), g, b, lds, st, a);
   else if (net->hidden == 64) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IJFO>), g, b, lds, st, a);
@@ -661,14 +711,17 @@ extern "C" int ppo_lstm_head_grad(const ppo_lstm_net* net, const float* latent, 
 
 // ---- one BPTT step (gate order i,f,o,u).  One wave per 16-row tile; LDS: dz [16][4*NH + 2]
 template <int NH>
-__global__ void __launch_bounds__(64) ppo_lstm_bwd_step_kernel(const float* wh, int n, const float* dlat, const float* mask,
-                                                               const float* gates, const float* cprev, const float* tanhc, float* dh_c,
-                                                               float* dc_c, float* dz_out) {
-  constexpr int ZS = 4 * NH + 2;
-  float* dzb = smem_f;
-  const int lane = threadIdx.x, r0 = blockIdx.x * 16;
-  // elementwise part: thread e -> (row, unit)
-  for (int e = lane; e < 16 * NH; e += WAVE) {
+__global__ void __launch_bounds__(256) ppo_lstm_bwd_step_kernel(const float* wh, int n, const float* dlat, const float* mask,
+                                                                const float* gates, const float* cprev, const float* tanhc, float* dh_c,
+                                                                float* dc_c, float* dz_out) {
+  // four waves per 16-row tile: the elementwise part is spread over all 256 threads, the contraction dh_prev = dz * wh^T
+  // over k is split in four (wave w contracts k in [w NH, (w+1) NH)) and the partial tiles are summed through LDS in wave
+  // order -- a quarter of the dependent weight-load round trips per wave
+  constexpr int ZS = 4 * NH + 2, PS = NH;
+  float* dzb = smem_f;                 // [16][ZS]
+  float* part = smem_f;                // [4][16][PS] partial dh tiles, over dzb once every wave is done reading it
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r0 = blockIdx.x * 16;
+  for (int e = tid; e < 16 * NH; e += 256) {
     const int r = e / NH, j = e - r * NH, row = r0 + r;
     float dzi = 0, dzf = 0, dzo = 0, dzu = 0;
     if (row < n) {
@@ -685,26 +738,54 @@ __global__ void __launch_bounds__(64) ppo_lstm_bwd_step_kernel(const float* wh, 
     }
     dzb[r * ZS + j] = dzi; dzb[r * ZS + NH + j] = dzf; dzb[r * ZS + 2 * NH + j] = dzo; dzb[r * ZS + 3 * NH + j] = dzu;
   }
-  wave_sync();
-  // dh_prev = dz * wh^T : [16 x 4NH] x [4NH x NH]
+  __syncthreads();
   const int i = lane & 15, kq = lane >> 4;
   constexpr int NT = NH / 16;
   f32x4 acc[NT];
 #pragma unroll
   for (int ct = 0; ct < NT; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
-  for (int k0 = 0; k0 < 4 * NH; k0 += 4) {
-    const int k = k0 + kq;
-    const float av = dzb[i * ZS + k];
+  // B[k][col] = wh[col][k]: a lane reads 16 contiguous bytes of its column (k = k0 + 4 kq .. + 3) and feeds them to four
+  // k-steps (step r contracts k0 + 4 kq' + r over the four kq'), the next batch's loads in flight meanwhile
+  auto fetchw = [&](int k0, float (&av)[4], float (&b)[NT][4]) {
+    const int k = k0 + 4 * kq;
 #pragma unroll
-    for (int ct = 0; ct < NT; ct++) acc[ct] = MFMA(av, wh[(size_t)(ct * 16 + i) * 4 * NH + k], acc[ct]);   // B[k][col] = wh[col][k]
+    for (int r = 0; r < 4; r++) av[r] = dzb[i * ZS + k + r];
+#pragma unroll
+    for (int ct = 0; ct < NT; ct++) {
+      const float4 w4 = *reinterpret_cast<const float4*>(wh + (size_t)(ct * 16 + i) * 4 * NH + k);
+      b[ct][0] = w4.x; b[ct][1] = w4.y; b[ct][2] = w4.z; b[ct][3] = w4.w;
+    }
+  };
+  {
+    const int kbeg = wid * NH, kend = kbeg + NH;   // NH is a multiple of 32
+    float av0[4], av1[4], bw0[NT][4], bw1[NT][4];
+    fetchw(kbeg, av0, bw0);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+      fetchw(k0 + 16, av1, bw1);
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++) acc[ct] = MFMA(av0[r], bw0[ct][r], acc[ct]);
+      if (k0 + 32 < kend) fetchw(k0 + 32, av0, bw0);
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++) acc[ct] = MFMA(av1[r], bw1[ct][r], acc[ct]);
+    }
   }
+  __syncthreads();
 #pragma unroll
   for (int ct = 0; ct < NT; ct++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = r0 + 4 * kq + r;
-      if (row < n) dh_c[(size_t)row * NH + ct * 16 + i] = acc[ct][r] * (mask ? 1.0f - mask[row] : 1.0f);
+    for (int r = 0; r < 4; r++) part[(wid * 16 + 4 * kq + r) * PS + ct * 16 + i] = acc[ct][r];
+  __syncthreads();
+  for (int e = tid; e < 16 * NH; e += 256) {
+    const int r = e / NH, j = e - r * NH, row = r0 + r;
+    if (row < n) {
+      const float sum = ((part[r * PS + j] + part[(16 + r) * PS + j]) + part[(32 + r) * PS + j]) + part[(48 + r) * PS + j];
+      dh_c[(size_t)row * NH + j] = sum * (mask ? 1.0f - mask[row] : 1.0f);
     }
+  }
 }
 extern "C" int ppo_lstm_bwd_step(const ppo_lstm_net* net, int n, const float* dlatent_t, const float* mask_t, const float* gates_t,
                                  const float* cprev_t, const float* tanhc_t, float* dh_carry, float* dc_carry, float* dz_out, void* stream) {
@@ -714,10 +795,10 @@ extern "C" int ppo_lstm_bwd_step(const ppo_lstm_net* net, int n, const float* dl
   const int tiles = (n + 15) / 16;
   const size_t lds = (size_t)16 * (4 * net->hidden + 2) * sizeof(float);
   if (net->hidden == 64)
-    hipLaunchKernelGGL(ppo_lstm_bwd_step_kernel<64>, dim3(tiles), dim3(64), lds, (hipStream_t)stream, net->wh, n, dlatent_t, mask_t, gates_t,
+    hipLaunchKernelGGL(ppo_lstm_bwd_step_kernel<64>, dim3(tiles), dim3(256), lds, (hipStream_t)stream, net->wh, n, dlatent_t, mask_t, gates_t,
                        cprev_t, tanhc_t, dh_carry, dc_carry, dz_out);
   else
-    hipLaunchKernelGGL(ppo_lstm_bwd_step_kernel<128>, dim3(tiles), dim3(64), lds, (hipStream_t)stream, net->wh, n, dlatent_t, mask_t, gates_t,
+    hipLaunchKernelGGL(ppo_lstm_bwd_step_kernel<128>, dim3(tiles), dim3(256), lds, (hipStream_t)stream, net->wh, n, dlatent_t, mask_t, gates_t,
                        cprev_t, tanhc_t, dh_carry, dc_carry, dz_out);
   HIPCHK(hipGetLastError());
   return 0;

@@ -28,6 +28,7 @@ class LstmSpec(object):
 class LstmPPOModel(object):
     loss_names = ["policy_loss", "value_loss", "policy_entropy", "approxkl", "clipfrac"]
     recurrent = True
+    use_graph = True      # single-GPU training on device tensors: the ~2T+12 launches of a minibatch step replay from a HIP graph
 
     def __init__(self, *, policy, ob_space=None, ac_space=None, nbatch_act=None, nbatch_train=None, nsteps=None, ent_coef=0.0,
                  vf_coef=0.5, max_grad_norm=0.5, microbatch_size=None, trainable=True, model_scope="", device=0, comm=None):
@@ -59,6 +60,7 @@ class LstmPPOModel(object):
             self.gviews = self._split(self.grads)
             self.stats = torch.zeros(ppo_capi.NSTATS, dtype=torch.float64, device=self.device)
             self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
+            self._graphs = {}
 
     class _X:
         class dtype:
@@ -194,6 +196,59 @@ class LstmPPOModel(object):
         g[7].copy_(dvalue.sum().view(1))
         return state
 
+    def _loss_step(self, cliprange, obs, ret, val, masks, actions, neglogpacs, IS_weight, states, T, world):
+        """Advantage normalisation (model.py:180-185) + loss_and_grads: everything of a minibatch step before the optimiser."""
+        t = self._t
+        L = ppo_capi.lib()
+        nrow = ret.numel()
+        st = t.cuda.current_stream(self.device).cuda_stream
+        adv = t.empty(nrow, dtype=t.float32, device=self.device)
+        ppo_capi.chk(L.ppo_adv_moments(ret.data_ptr(), val.data_ptr(), None, nrow, self.moments.data_ptr(), st))
+        sdist.allreduce_moments(self.moments, self.comm)                                # global advantage normalisation
+        ppo_capi.chk(L.ppo_adv_normalize(ret.data_ptr(), val.data_ptr(), None, nrow, self.moments.data_ptr(), adv.data_ptr(), st))
+        self.loss_and_grads(cliprange, obs, ret, masks, actions, adv, neglogpacs, IS_weight, states, T, world=world)
+
+    def _graph_step(self, cliprange, tensors, T):
+        """Replay ``_loss_step`` from a HIP graph captured once per (minibatch shape, cliprange): the inputs are copied into
+        buffers owned by the graph, the 2T+12 kernel launches and GEMMs of the step then cost one launch on the host.
+        Returns False (after switching the graph path off) if capture is not possible here."""
+        t = self._t
+        key = (tuple(tuple(x.shape) for x in tensors), tuple(x.dtype for x in tensors), int(T), float(cliprange))
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 2:
+                self._graphs.clear()
+            try:
+                static = [t.empty(x.shape, dtype=x.dtype, device=self.device) for x in tensors]
+                for d, x in zip(static, tensors):
+                    d.copy_(x)
+
+                def body():
+                    obs, returns, masks, actions, values, neglogpacs, IS_weight, states = static
+                    self._loss_step(cliprange, obs, returns.contiguous(), values.contiguous(), masks, actions, neglogpacs, IS_weight,
+                                    states, T, 1)
+                side = t.cuda.Stream(device=self.device)
+                side.wait_stream(t.cuda.current_stream(self.device))
+                with t.cuda.stream(side):          # warm-up outside the capture (GEMM workspaces, kernel attributes, allocator)
+                    body()
+                t.cuda.current_stream(self.device).wait_stream(side)
+                t.cuda.synchronize(self.device)
+                graph = t.cuda.CUDAGraph()
+                with t.cuda.graph(graph):
+                    body()
+                ent = self._graphs[key] = dict(graph=graph, static=static)
+            except Exception as e:                 # capture unsupported here: eager launches from now on
+                type(self).use_graph = False
+                self._graphs.clear()
+                import warnings
+                warnings.warn("HIP graph capture of the recurrent PPO step failed (%r); using eager launches" % (e,))
+                return False
+        else:
+            for d, x in zip(ent["static"], tensors):
+                d.copy_(x)
+        ent["graph"].replay()
+        return True
+
     def train(self, lr, cliprange, obs, returns, masks, actions, values, neglogpacs, rewards, IS_weight, states=None, nsteps=None):
         if not self.trainable:
             raise RuntimeError("model built with trainable=False")
@@ -203,15 +258,13 @@ class LstmPPOModel(object):
         L = ppo_capi.lib()
         np_in = not t.is_tensor(obs)
         T = int(nsteps or self.nsteps)
-        ret, val = self._dev(returns).contiguous(), self._dev(values).contiguous()
-        nrow = ret.numel()
-        st = t.cuda.current_stream(self.device).cuda_stream
-        adv = t.empty(nrow, dtype=t.float32, device=self.device)                        # model.py:180-185
         world = 1 if self.comm is None else t.distributed.get_world_size(self.comm)
-        ppo_capi.chk(L.ppo_adv_moments(ret.data_ptr(), val.data_ptr(), None, nrow, self.moments.data_ptr(), st))
-        sdist.allreduce_moments(self.moments, self.comm)                                # global advantage normalisation
-        ppo_capi.chk(L.ppo_adv_normalize(ret.data_ptr(), val.data_ptr(), None, nrow, self.moments.data_ptr(), adv.data_ptr(), st))
-        self.loss_and_grads(cliprange, obs, ret, masks, actions, adv, neglogpacs, IS_weight, states, T, world=world)
+        tensors = (obs, returns, masks, actions, values, neglogpacs, IS_weight, states)
+        if not (self.use_graph and self.comm is None and all(t.is_tensor(x) for x in tensors)
+                and self._graph_step(cliprange, tensors, T)):
+            ret, val = self._dev(returns).contiguous(), self._dev(values).contiguous()
+            self._loss_step(cliprange, obs, ret, val, masks, actions, neglogpacs, IS_weight, states, T, world)
+        st = t.cuda.current_stream(self.device).cuda_stream
         if self.comm is not None:            # ONE fused collective per optimiser step: [flat grad | loss sums] (equal shards per rank)
             self.grads[self.P:] = self.stats.to(t.float32)
             sdist.allreduce_fused(self.grads, self.comm)

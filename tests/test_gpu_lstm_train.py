@@ -92,6 +92,31 @@ def test_train_step_matches_oracle_adam_and_reduces_loss():
     assert out[1] < 0.8 * v0
 
 
+def test_graph_replay_matches_eager_recurrent_steps():
+    """The recurrent minibatch step replayed from a HIP graph (device tensors in, single GPU) leaves the same parameters
+    and loss statistics as the eager launches, over several steps with changing inputs."""
+    rng = np.random.default_rng(11)
+    T, n, D, A, H = 6, 20, 23, 5, 64
+    obs, masks, actions, returns, values, S0 = _batch(rng, T, n, D, A, H)
+    flat = lambda x: np.ascontiguousarray(x).reshape(n * T, *x.shape[2:])
+    dev = lambda x, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(x)).to("cuda", dt)
+    base = [dev(flat(obs)), dev(flat(returns)), dev(flat(masks).astype(np.float32)), dev(flat(actions)), dev(flat(values))]
+    old = dev(rng.normal(5.0, 0.1, n * T)); w = dev(np.ones(n * T)); S = dev(S0)
+    res = []
+    for use_graph in (True, False):
+        np.random.seed(3)
+        m = lstm_model.LstmPPOModel(policy=lstm_model.LstmSpec(D, A, H), ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, nbatch_act=n, nsteps=T)
+        m.use_graph = use_graph
+        outs = []
+        for k in range(4):
+            o = base[0] + 0.01 * k                    # new input values every step: the graph must read its copies, not stale data
+            outs.append(m.train(1e-3, 0.2, o, base[1], base[2], base[3], base[4], old, None, w, states=S)[:5])
+        assert (len(m._graphs) == 1) == use_graph
+        res.append((m.params.clone(), np.asarray(outs, np.float64)))
+    assert torch.equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 def test_learn_with_lstm_policy_smoke(tmp_path):
     """Config-5-like plumbing on one GPU: Ant-vs-Ant, LSTM(128) learner and opponent, whole-sequence minibatches."""
     from robosumo_selfplay_amd import alg_ppo
