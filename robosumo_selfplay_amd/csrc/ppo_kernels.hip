@@ -317,54 +317,74 @@ __device__ __forceinline__ void gauss_head(const float* params, const ParamLayou
   }
 }
 
-__global__ void __launch_bounds__(64) ppo_selfplay_kernel(SelfplayArgs a) {
-  const int lane = threadIdx.x, side = blockIdx.y, r0 = blockIdx.x * 16;
+__global__ void __launch_bounds__(192) ppo_selfplay_kernel(SelfplayArgs a) {
+  // three waves per (tile, side): wave 0 the acting net's policy trunk (samples), wave 1 the scoring net's policy trunk,
+  // wave 2 the learner's value trunk -- in parallel on the shared observation tile; the sampled action reaches wave 1
+  // through LDS.  (One wave running the three trunks back to back took 45 us between two env steps of a group.)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, side = blockIdx.y, r0 = blockIdx.x * 16;
   if (r0 >= a.n) return;
   const int XS = a.XS, D = a.L.D, A = a.L.A;
-  float *xbuf = smem_f, *h1 = xbuf + 16 * XS, *h2 = h1 + 16 * HS;
+  float* xbuf = smem_f;
+  float* actl = xbuf + 16 * XS;                       // [16][17] sampled actions
+  float* h1 = actl + 16 * 17 + wid * (2 * 16 * HS);   // per-wave activation tiles
+  float* h2 = h1 + 16 * HS;
   const int i = lane & 15, kq = lane >> 4;
-  stage_x(xbuf, XS, a.obs + (size_t)side * a.agent_stride, a.env_stride, D, nullptr, r0, a.n, lane);
-  wave_sync();
+  stage_x(xbuf, XS, a.obs + (size_t)side * a.agent_stride, a.env_stride, D, nullptr, r0, a.n, tid, nullptr, nullptr, 0.0f, 192);
+  __syncthreads();
   const float* actor = side == 0 ? a.learner : a.opponent;
   const float* scorer = side == 0 ? a.opponent : a.learner;
-  float act[4], nlp_actor[4], nlp_scorer[4];
-  {
-    f32x4 mean = trunk_forward<false>(pi_net(actor, a.L), xbuf, XS, D, h1, h2, lane);
-    gauss_head(actor, a.L, mean, side == 0 ? a.noise0 : a.noise1, r0, a.n, lane, act, nlp_actor);
-  }
-  wave_sync();
-  {
-    f32x4 mean = trunk_forward<false>(pi_net(scorer, a.L), xbuf, XS, D, h1, h2, lane);
-    gauss_head(scorer, a.L, mean, nullptr, r0, a.n, lane, act, nlp_scorer);
-  }
-  wave_sync();
-  const f32x4 v = trunk_forward<false>(vf_net(a.learner, a.L), xbuf, XS, D, h1, h2, lane);
-  float* act_out = side == 0 ? a.act0 : a.act1;
   float* nlp_out = side == 0 ? a.nlp0 : a.nlp1;        // the LEARNER's neglogp of the action taken on this side
   float* onlp_out = side == 0 ? a.onlp0 : a.onlp1;     // the OPPONENT's
-  float* val_out = side == 0 ? a.val0 : a.val1;
+  float act[4] = {0, 0, 0, 0}, nlp[4];
+  f32x4 head = (f32x4){0, 0, 0, 0};
+  if (wid == 0) {
+    head = trunk_forward<false>(pi_net(actor, a.L), xbuf, XS, D, h1, h2, lane);
+    gauss_head(actor, a.L, head, side == 0 ? a.noise0 : a.noise1, r0, a.n, lane, act, nlp);
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = r0 + 4 * kq + r;
-    if (row >= a.n) continue;
-    if (i < A) {
-      act_out[(size_t)row * A + i] = act[r];
-      a.act_env[((size_t)row * 2 + side) * A + i] = act[r];
+    for (int r = 0; r < 4; r++) actl[(4 * kq + r) * 17 + i] = act[r];
+  } else if (wid == 1) {
+    head = trunk_forward<false>(pi_net(scorer, a.L), xbuf, XS, D, h1, h2, lane);
+  } else {
+    head = trunk_forward<false>(vf_net(a.learner, a.L), xbuf, XS, D, h1, h2, lane);
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float* act_out = side == 0 ? a.act0 : a.act1;
+    float* out = side == 0 ? nlp_out : onlp_out;       // the acting net is the learner on side 0, the opponent on side 1
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 4 * kq + r;
+      if (row >= a.n) continue;
+      if (i < A) {
+        act_out[(size_t)row * A + i] = act[r];
+        a.act_env[((size_t)row * 2 + side) * A + i] = act[r];
+      }
+      if (i == 0) out[row] = nlp[r];
     }
+  } else if (wid == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) act[r] = actl[(4 * kq + r) * 17 + i];
+    gauss_head(scorer, a.L, head, nullptr, r0, a.n, lane, act, nlp);
+    float* out = side == 0 ? onlp_out : nlp_out;
     if (i == 0) {
-      nlp_out[row] = side == 0 ? nlp_actor[r] : nlp_scorer[r];
-      onlp_out[row] = side == 0 ? nlp_scorer[r] : nlp_actor[r];
-      val_out[row] = v[r];
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const int row = r0 + 4 * kq + r; if (row < a.n) out[row] = nlp[r]; }
+    }
+  } else {
+    float* val_out = side == 0 ? a.val0 : a.val1;
+    if (i == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const int row = r0 + 4 * kq + r; if (row < a.n) val_out[row] = head[r]; }
     }
   }
   // rollout records of the inputs: the staged observations and the done flags the step started from
   float* obs_out = side == 0 ? a.obs_out0 : a.obs_out1;
   if (obs_out) {
     for (int r = 0; r < 16 && r0 + r < a.n; r++)
-      for (int c = lane; c < D; c += WAVE) obs_out[(size_t)(r0 + r) * D + c] = xbuf[r * XS + c];
+      for (int c = tid; c < D; c += 192) obs_out[(size_t)(r0 + r) * D + c] = xbuf[r * XS + c];
   }
   uint8_t* done_out = side == 0 ? a.done_out0 : a.done_out1;
-  if (done_out && a.done_in && lane < 16 && r0 + lane < a.n) done_out[r0 + lane] = a.done_in[(size_t)(r0 + lane) * 2 + side];
+  if (done_out && a.done_in && tid < 16 && r0 + tid < a.n) done_out[r0 + tid] = a.done_in[(size_t)(r0 + tid) * 2 + side];
 }
 
 extern "C" int ppo_selfplay_forward(const float* learner_params, const float* opponent_params, const float* obs, int n, int env_stride,
@@ -383,13 +403,13 @@ extern "C" int ppo_selfplay_forward(const float* learner_params, const float* op
   a.done_out0 = out_done ? out_done[0] : nullptr; a.done_out1 = out_done ? out_done[1] : nullptr;
   a.n = n; a.env_stride = env_stride; a.agent_stride = agent_stride; a.XS = x_stride(ob_dim);
   a.L = make_layout(ob_dim, ac_dim);
-  size_t lds = (size_t)(16 * a.XS + 2 * 16 * HS) * sizeof(float);
+  size_t lds = (size_t)(16 * a.XS + 16 * 17 + 3 * 2 * 16 * HS) * sizeof(float);
   static thread_local size_t lds_set = 0;
   if (lds > 64 * 1024 && lds > lds_set) {
     HIPCHK(hipFuncSetAttribute((const void*)ppo_selfplay_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
-  hipLaunchKernelGGL(ppo_selfplay_kernel, dim3((n + 15) / 16, 2), dim3(64), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ppo_selfplay_kernel, dim3((n + 15) / 16, 2), dim3(192), lds, (hipStream_t)stream, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
