@@ -206,8 +206,13 @@ class Runner(AbstractEnvRunner):
         t = self._t
         n = sl.stop - sl.start
         D, A = learner.spec.ob_dim, learner.spec.ac_dim
-        noise0 = t.randn((n, A), generator=learner.gen, device=self.device, dtype=t.float32)
-        noise1 = t.randn((n, A), generator=opp.gen, device=self.device, dtype=t.float32)
+        # action noise of this group for the whole buffer, drawn at its first step (two launches per rollout instead of two per
+        # step between the env steps); each acting model's own generator, as in ``PolicyWithValue.evaluate``
+        key = ("noise", sl.start)
+        if s == 0 or key not in B:
+            B[key] = (t.randn((B["T"], n, A), generator=learner.gen, device=self.device, dtype=t.float32),
+                      t.randn((B["T"], n, A), generator=opp.gen, device=self.device, dtype=t.float32))
+        noise0, noise1 = B[key][0][s], B[key][1][s]
         outs = [B["obs"][0, s, sl], B["obs"][1, s, sl], B["act"][0, s, sl], B["act"][1, s, sl], B["nlp"][0, s, sl], B["nlp"][1, s, sl],
                 B["onlp"][0, s, sl], B["onlp"][1, s, sl], B["val"][0, s, sl], B["val"][1, s, sl]]
         fp = (C.c_void_p * 10)(*[x.data_ptr() for x in outs])
