@@ -19,10 +19,12 @@ import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from robosumo_selfplay_amd import hostcfg  # noqa: E402  (first: caps the host thread pools at the cgroup CPU quota)
+
+hostcfg.apply()
+import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -64,8 +66,22 @@ def main():
     ap.add_argument("--cpu-sample-envs", type=int, default=512)
     ap.add_argument("--cpu-sample-steps", type=int, default=60)
     ap.add_argument("--ppo-nsteps", type=int, default=128, help="rollout length of the PPO2 update timed after the main region (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(os.cpu_count(), 16): a 1-GPU box's CPU share")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the cgroup CPU quota of this job (hostcfg.cpu_quota)")
+    ap.add_argument("--state-warmup", type=int, default=100,
+                    help="untimed rollout steps that bring the env states from the reset law to the steady workload (SURVEY.md 8(d): >= 100)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one rank per GPU through torch.distributed.run, started BEFORE this process touches a GPU (a process that
+        # has initialised HIP must never exec; children are ordinary subprocesses).  Rank 0's JSON line passes through.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     import torch
     from robosumo_selfplay_amd import mjcf
@@ -119,8 +135,13 @@ def main():
 
     ring = 8
     B = runner._alloc_device(ring)
-    for k in range(args.warmup):
+    # workload priming (not a timing knob): the reset law drops every agent from z = 1.25 at the same instant; >= 100 rollout
+    # steps under the initial policy's N(0,1)-scale actions spread the episodes out and make contacts active
+    for k in range(args.state_warmup):
         runner._step_device(B, k % ring, alpha)
+    torch.cuda.synchronize(dev)
+    for k in range(args.warmup):                                   # timing warm-up
+        runner._step_device(B, (args.state_warmup + k) % ring, alpha)
     torch.cuda.synchronize(dev)
     st0 = env.stats()
     states = None
@@ -132,13 +153,16 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     barrier()
+    thr0 = hostcfg.throttle_stats()
     t0 = time.perf_counter()
     ev_every = int(os.environ.get("BENCH_EVENT_EVERY", "1"))       # HIP events around the env launch of every n-th step (0 = none)
     timed = [k for k in range(args.steps) if ev_every and k % ev_every == 0]
+    k0 = args.state_warmup + args.warmup
     for k in range(args.steps):
-        runner._step_device(B, k % ring, alpha, env_events=(ev0[k], ev1[k]) if ev_every and k % ev_every == 0 else None)
+        runner._step_device(B, (k0 + k) % ring, alpha, env_events=(ev0[k], ev1[k]) if ev_every and k % ev_every == 0 else None)
     barrier()
     dt = time.perf_counter() - t0
+    thr1 = hostcfg.throttle_stats()
     kern_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in timed])) if timed else float("nan")
     st1 = env.stats()
     sample_acts = [B["act"][:, k].permute(1, 0, 2).contiguous() for k in range(ring)]   # [N, 2, A] per step
@@ -197,6 +221,7 @@ def main():
                                    "(5 policy/value evaluations + env step of frame_skip 5 x RK4 + reward mix), random-init "
                                    "networks, auto-reset on" % (args.env_id, N),
                        "ppo2": ppo,
+                       "state_warmup_steps": args.state_warmup,
                        "envs_per_gpu": N, "env_groups_per_gpu": env.groups, "total_envs": N * world, "parallelism": "env-shard x%d" % world,
                        "mean_contacts_per_forward": (st1["contacts"] - st0["contacts"]) / nfwd,
                        "mean_newton_iters_per_forward": (st1["newton"] - st0["newton"]) / nfwd,
@@ -208,8 +233,11 @@ def main():
                          "aggregate_achieved": B * value / max(1, world) / 1e9,
                          "note": "latency/ALU-bound physics: ~20 forward-dynamics solves per 2.4 KB of state traffic"},
         }
+        out["host"] = {"cpu_model": hostcfg.cpu_model(), "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": hostcfg.cpu_quota(),
+                       "pool_threads": hostcfg.apply(),
+                       "throttled_periods_in_timed_region": None if thr0 is None or thr1 is None else thr1[0] - thr0[0]}
         if states is not None:
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            threads = args.cpu_threads or hostcfg.cpu_quota()
             cpu_acts = [a[:states[0].shape[0]].cpu().numpy() for a in sample_acts]
             v = cpu_baseline(model, states, cpu_acts, args.cpu_sample_steps, threads)
             out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",

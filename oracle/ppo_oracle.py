@@ -433,3 +433,66 @@ def lstm_ppo_loss_and_grads(params, obs, masks, actions, advs, returns, oldneglo
         dc = dct * f * (1 - m)
     stats = np.array([pg_loss, vf_loss, ent, approxkl, clipfrac])
     return loss, stats, [g_wx, g_wh, g_b, g_pw, g_pb, dlogstd, g_vw, g_vb], np.concatenate([c, h], axis=1)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# per-update glue of the self-play driver: reference alg_ppo.py:217-244 (opponent selection), :258-344 (ratio hygiene,
+# usable opponent samples, batch assembly, weights), :355-398 (minibatch order).  Plain numpy in the reference too, so the
+# restatement follows it statement by statement; pinned only by being that short (no fixture in the reference).
+# ----------------------------------------------------------------------------------------------------------
+def ratio_hygiene(ratio, clip_ratio):
+    """alg_ppo.py:258-280, one of the three identical blocks: NaN -> clip_ratio, mean BEFORE the clip, fraction above the
+    clip, then clip to [0, clip_ratio].  Returns (cleaned, mean, clip_frac)."""
+    r = np.array(ratio, copy=True)
+    r[np.isnan(r)] = clip_ratio                              # :262 / :270 / :277
+    mean = r.mean()                                          # :263
+    frac = (r > clip_ratio).mean()                           # :264
+    return np.clip(r, 0.0, clip_ratio), mean, frac           # :265
+
+
+def update_batch(obs, returns, masks, actions, values, neglogpacs, rewards, off_policy_ratio, off_env_ratio, total_ratio, *,
+                 nbatch, rho_bar, neglogp_threshold, use_opponent_data, vgap=None, version_gap=None):
+    """alg_ppo.py:258-344.  Inputs are Runner.run outputs ([2, nbatch, ...] arrays and [nbatch] ratios).  Returns a dict with
+    the minibatch source arrays (obs, returns, masks, actions, values, neglogpacs, rewards, weights), the cleaned ratios,
+    their logged statistics, ``usable_index`` and ``useful_ratio``."""
+    out = {}
+    opr, out["off_policy_ratio_mean"], out["off_policy_clip_frac"] = ratio_hygiene(off_policy_ratio, rho_bar)
+    oer, out["off_env_ratio_mean"], out["off_env_clip_frac"] = ratio_hygiene(off_env_ratio, rho_bar)
+    tr, out["total_ratio_mean"], out["total_clip_frac"] = ratio_hygiene(total_ratio, rho_bar)
+    usable = np.where(neglogpacs[1] < neglogp_threshold)[0]                                     # :286
+    out["useful_ratio"] = 1.0 - (1.0 - len(usable) / len(neglogpacs[1]))                        # :288-289
+    arrs = (obs, returns, masks, actions, values, neglogpacs, rewards)
+    if use_opponent_data is None:                                                                # :325-327
+        arrs = [x[0] for x in arrs]
+    elif vgap is not None and version_gap is not None and version_gap > vgap:                   # :328-330
+        arrs = [x[0] for x in arrs]
+    else:                                                                                        # :331-335
+        arrs = [np.concatenate([x[0], x[1, usable]], axis=0) for x in arrs]
+    if use_opponent_data is None:                                                                # :337-344
+        weights = np.ones(nbatch, dtype=np.float32)
+    elif use_opponent_data == "direct":
+        weights = np.ones(arrs[0].shape[0], dtype=np.float32)
+    elif use_opponent_data == "off_policy":
+        weights = np.concatenate([np.ones(nbatch, dtype=np.float32), opr[usable]])
+    elif use_opponent_data == "both":
+        weights = np.concatenate([np.ones(nbatch, dtype=np.float32), tr[usable]])
+    else:
+        raise ValueError(use_opponent_data)
+    for k, v in zip(("obs", "returns", "masks", "actions", "values", "neglogpacs", "rewards"), arrs):
+        out[k] = v
+    out.update(weights=weights, usable_index=usable, off_policy_ratio=opr, off_env_ratio=oer, total_ratio=tr)
+    return out
+
+
+def opponent_selection_probs(action_prob, new_action_probs):
+    """alg_ppo.py:227-244 ('ours'): ratio divergence of every candidate snapshot against the current opponent on the last
+    rollout's opponent samples, normalised into sampling probabilities.  ``action_prob`` [n] and ``new_action_probs`` [K, n]
+    are what ``act_model.action_probability`` returns (i.e. neglogp values: the reference divides them as they are)."""
+    rd = np.array([np.abs(nap / action_prob - 1.0).mean() for nap in new_action_probs])        # :237-238
+    return rd / rd.sum()                                                                        # :241-242
+
+
+def minibatch_slices(nsamp, nbatch_train):
+    """alg_ppo.py:378-380: consecutive slices of the shuffled index vector; the last one is short when opponent data made
+    ``nsamp`` a non-multiple of ``nbatch_train``."""
+    return [(s, min(s + nbatch_train, nsamp)) for s in range(0, nsamp, nbatch_train)]

@@ -3,6 +3,10 @@
 See DESIGN.md for scope.  Importing this package does not touch the GPU and does not load the HIP
 library; ``robosumo_selfplay_amd.capi`` does that lazily and fails loudly when it is missing.
 """
-from .mjcf import SumoModel, compile_env, compile_scene, load_model, registry  # noqa: F401
+from . import hostcfg as _hostcfg
+
+_hostcfg.apply()          # cap BLAS / OpenMP / torch pools at the cgroup CPU quota BEFORE numpy spawns them (see hostcfg.py)
+
+from .mjcf import SumoModel, compile_env, compile_scene, load_model, registry  # noqa: E402,F401
 
 __all__ = ["SumoModel", "compile_env", "compile_scene", "load_model", "registry"]

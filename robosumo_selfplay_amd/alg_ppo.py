@@ -37,6 +37,52 @@ def explained_variance(ypred, y):
     return np.nan if vary == 0 else 1 - np.var(y - ypred) / vary
 
 
+def clean_ratio(r, clip_ratio):
+    """alg_ppo.py:258-280 (one of its three identical blocks) on a device tensor: NaN -> clip_ratio, the mean and the
+    fraction above the clip taken BEFORE clipping, then clamp to [0, clip_ratio].  Returns (cleaned, mean, clip_frac)."""
+    import torch
+    r = torch.where(torch.isnan(r), torch.full_like(r, clip_ratio), r)
+    return r.clamp(0.0, clip_ratio), float(r.mean().item()), float((r > clip_ratio).float().mean().item())
+
+
+def assemble_update_batch(obs, returns, masks, actions, values, neglogpacs, rewards, off_policy_ratio, total_ratio, *, nbatch,
+                          neglogp_threshold, use_opponent_data, vgap=None, version_gap=None):
+    """alg_ppo.py:286-344 on device tensors: the opponent samples whose learner-neglogp is below the threshold
+    (``usable_index``), agent 0's rollout alone or followed by agent 1's usable rows, and the importance weights of
+    ``direct`` / ``off_policy`` / ``both``.  The ratios are the CLEANED ones.  Returns a dict like the oracle's
+    ``update_batch`` (oracle/ppo_oracle.py) -- that is what tests compare it with."""
+    import torch
+    dev = returns.device
+    usable = torch.nonzero(neglogpacs[1] < neglogp_threshold).flatten()
+    names = ("obs", "returns", "masks", "actions", "values", "neglogpacs", "rewards")
+    arrs = (obs, returns, masks, actions, values, neglogpacs, rewards)
+    use_opp = use_opponent_data is not None and not (vgap is not None and version_gap is not None and version_gap > vgap)
+    if not use_opp:                                                      # alg_ppo.py:325-330
+        out = {k: x[0] for k, x in zip(names, arrs)}
+    else:                                                                # :331-335
+        out = {k: torch.cat([x[0], x[1][usable]], dim=0) for k, x in zip(names, arrs)}
+    ones = torch.ones(nbatch, dtype=torch.float32, device=dev)
+    if use_opponent_data is None:                                        # :337-344, keyed on the mode alone like the reference
+        weights = ones
+    elif use_opponent_data == "direct":
+        weights = torch.ones(out["obs"].shape[0], dtype=torch.float32, device=dev)
+    elif use_opponent_data == "off_policy":
+        weights = torch.cat([ones, off_policy_ratio[usable]])
+    elif use_opponent_data == "both":
+        weights = torch.cat([ones, total_ratio[usable]])
+    else:
+        raise ValueError("use_opponent_data %r" % (use_opponent_data,))
+    out.update(weights=weights, usable_index=usable, useful_ratio=float(usable.numel()) / float(neglogpacs[1].numel()))
+    return out
+
+
+def selection_probs(action_prob, new_action_probs):
+    """alg_ppo.py:237-242: mean |new/old - 1| of the candidates' ``action_probability`` outputs on the last rollout's opponent
+    samples, normalised to sampling probabilities (uniform when every candidate equals the current opponent)."""
+    rd = np.array([float((nap / action_prob - 1.0).abs().mean().item()) for nap in new_action_probs])
+    return rd / rd.sum() if rd.sum() > 0 else np.full(len(rd), 1.0 / len(rd))
+
+
 def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_data=None, eval_env=None, seed=None, nsteps=2048,
           ent_coef=0.0, lr=3e-4, vf_coef=0.5, max_grad_norm=0.5, gamma=0.99, lam=0.95, rho_bar=1.0, c_bar=1.0, log_interval=10,
           nminibatches=4, noptepochs=4, cliprange=0.2, save_interval=1, load_path=None, model_fn=None, update_fn=None, init_fn=None,
@@ -92,7 +138,8 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
     if init_fn is not None:
         init_fn()
     tfirststart = time.perf_counter()
-    history = dict(version_gap=[], off_policy_ratio_mean=[], off_env_ratio_mean=[], total_ratio_mean=[], ppo_clip_frac=[],
+    history = dict(version_gap=[], off_policy_ratio_mean=[], off_env_ratio_mean=[], total_ratio_mean=[], off_policy_ratio_clip_frac=[],
+                   off_env_ratio_clip_frac=[], total_ratio_clip_frac=[], useful_ratio=[], ppo_clip_frac=[],
                    approxkl=[], early_stop_info=[], lossvals=[], fps=[], rollout_s=[], update_s=[])
     nupdates = total_timesteps // nbatch
     idx_choice = 0
@@ -125,13 +172,11 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
             elif opponent_mode == "ours":                                # ratio-divergence sampling (:227-244)
                 ap = runner.models[1].act_model.action_probability(opponent_obs, given_action=opponent_actions)
                 sub = np.sort(np.random.choice(len(paths), 30, replace=False)) if len(paths) > 30 else np.arange(len(paths))
-                rd = []
+                naps = []
                 for i in sub:
                     model_util.load(paths[i])
-                    nap = model_util.act_model.action_probability(opponent_obs, given_action=opponent_actions)
-                    rd.append(float((nap / ap - 1.0).abs().mean().item()))
-                rd = np.array(rd)
-                rd = rd / rd.sum() if rd.sum() > 0 else np.full(len(rd), 1.0 / len(rd))
+                    naps.append(model_util.act_model.action_probability(opponent_obs, given_action=opponent_actions))
+                rd = selection_probs(ap, naps)
                 idx_choice = int(sub[np.random.choice(len(rd), 1, p=rd)[0]])
             else:
                 raise ValueError("opponent_mode %r" % (opponent_mode,))
@@ -153,32 +198,18 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         # un-scrambled opponent data for the 'ours' selector: rows = agent 1's (obs, action), env-major
         opponent_obs, opponent_actions = obs[1], actions[1]
         # ---- ratio hygiene (alg_ppo.py:258-280)
-        clip_ratio = rho_bar
-
-        def clean(r, key):
-            r = torch.where(torch.isnan(r), torch.full_like(r, clip_ratio), r)
-            history[key].append(float(r.mean().item()))
-            return r.clamp(0.0, clip_ratio)
-        off_policy_ratio = clean(off_policy_ratio, "off_policy_ratio_mean")
-        off_env_ratio = clean(off_env_ratio, "off_env_ratio_mean")
-        total_ratio = clean(total_ratio, "total_ratio_mean")
-        usable = torch.nonzero(neglogpacs[1] < neglogp_threshold).flatten()
-        use_opp = use_opponent_data is not None and not (vgap is not None and history["version_gap"] and history["version_gap"][-1] > vgap)
-        if not use_opp:                                                  # alg_ppo.py:325-327
-            b_obs, b_ret, b_act, b_val, b_nlp = obs[0], returns[0], actions[0], values[0], neglogpacs[0]
-            weights = torch.ones(nbatch, dtype=torch.float32, device=dev)
-        else:                                                            # :331-344
-            cat = lambda x: torch.cat([x[0], x[1][usable]], dim=0)
-            b_obs, b_ret, b_act, b_val, b_nlp = cat(obs), cat(returns), cat(actions), cat(values), cat(neglogpacs)
-            ones = torch.ones(nbatch, dtype=torch.float32, device=dev)
-            if use_opponent_data == "direct":
-                weights = torch.ones(b_obs.shape[0], dtype=torch.float32, device=dev)
-            elif use_opponent_data == "off_policy":
-                weights = torch.cat([ones, off_policy_ratio[usable]])
-            elif use_opponent_data == "both":
-                weights = torch.cat([ones, total_ratio[usable]])
-            else:
-                raise ValueError("use_opponent_data %r" % use_opponent_data)
+        off_policy_ratio, m, f = clean_ratio(off_policy_ratio, rho_bar)
+        history["off_policy_ratio_mean"].append(m); history["off_policy_ratio_clip_frac"].append(f)
+        off_env_ratio, m, f = clean_ratio(off_env_ratio, rho_bar)
+        history["off_env_ratio_mean"].append(m); history["off_env_ratio_clip_frac"].append(f)
+        total_ratio, m, f = clean_ratio(total_ratio, rho_bar)
+        history["total_ratio_mean"].append(m); history["total_ratio_clip_frac"].append(f)
+        # ---- usable opponent samples, batch assembly, weights (alg_ppo.py:286-344)
+        ub = assemble_update_batch(obs, returns, masks, actions, values, neglogpacs, rewards, off_policy_ratio, total_ratio,
+                                   nbatch=nbatch, neglogp_threshold=neglogp_threshold, use_opponent_data=use_opponent_data, vgap=vgap,
+                                   version_gap=history["version_gap"][-1] if history["version_gap"] else None)
+        b_obs, b_ret, b_act, b_val, b_nlp, weights = ub["obs"], ub["returns"], ub["actions"], ub["values"], ub["neglogpacs"], ub["weights"]
+        history["useful_ratio"].append(ub["useful_ratio"])
         b_obs = b_obs.contiguous()
         epinfobuf.extend(epinfos)
         # ---- minibatch SGD (alg_ppo.py:355-398)
