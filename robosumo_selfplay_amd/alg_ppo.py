@@ -49,8 +49,9 @@ def assemble_update_batch(obs, returns, masks, actions, values, neglogpacs, rewa
                           neglogp_threshold, use_opponent_data, vgap=None, version_gap=None):
     """alg_ppo.py:286-344 on device tensors: the opponent samples whose learner-neglogp is below the threshold
     (``usable_index``), agent 0's rollout alone or followed by agent 1's usable rows, and the importance weights of
-    ``direct`` / ``off_policy`` / ``both``.  The ratios are the CLEANED ones.  Returns a dict like the oracle's
-    ``update_batch`` (oracle/ppo_oracle.py) -- that is what tests compare it with."""
+    ``direct`` / ``off_policy`` / ``both``.  The ratios are the CLEANED ones.  Returns a dict of the minibatch
+    source arrays plus ``weights``, ``usable_index`` and ``useful_ratio`` (tests/test_update_glue.py checks it against a numpy
+    restatement of the cited lines)."""
     import torch
     dev = returns.device
     usable = torch.nonzero(neglogpacs[1] < neglogp_threshold).flatten()
