@@ -180,11 +180,13 @@ def main():
             obs_b, ret_b, act_b, val_b, nlp_b = out[0][0].contiguous(), out[1][0], out[3][0], out[4][0], out[5][0]
             nb = N * T
             wts = torch.ones(nb, dtype=torch.float32, device=dev)
+            learner.begin_update(obs_b, ret_b, act_b, val_b, nlp_b, wts)
             for ep in range(nep):
                 inds = torch.randperm(nb, device=dev).to(torch.int32)      # device-side shuffle (np.random.shuffle in alg_ppo.py:375)
                 for start in range(0, nb, nb // nmb):
                     mb = inds[start:start + nb // nmb]
                     learner.train_indexed(hp["lr"], hp["cliprange"], obs_b, ret_b, act_b, val_b, nlp_b, wts, mb, int(mb.numel()), sync=False)
+            learner.end_update()
             barrier()
             t_upd = time.perf_counter() - tu
             tt = torch.tensor([t_upd, t_roll], dtype=torch.float64, device=dev)

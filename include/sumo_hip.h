@@ -21,7 +21,10 @@
  * Shapes (E = num_envs, A = 2 agents, row-major):
  *   actions  float32 [E][A][act_stride]     raw policy outputs (clamped to ctrlrange inside, as MuJoCo does)
  *   obs      float32 [E][A][obs_stride]     agents.py:190-214 layout + time feature (sumo_env.py:68-70)
- *   info     float64 [E][A][8]              ctrl, lose, win, main, move, push, shaping, flags(bit0 winner, bit1 timeout)
+ *   info     float64 [E][A][8]              ctrl, lose, win, main, move, push, shaping, flags(bit0 winner, bit1 timeout,
+ *                                           bit2 diverged: the state failed MuJoCo's bad-value test -- NaN or |x| > 1e10 in
+ *                                           qpos/qvel/qacc, mujoco-py/mujoco_py/builder.py:351-369 raises there -- the step
+ *                                           then reports zero rewards, done, and the env auto-resets)
  *   done     uint8   [E][A]
  *   ep_r, ep_dr float64 [E]; ep_l int32 [E] episode return / dense return / length of agent 0, valid where done
  */
@@ -54,8 +57,9 @@ int sumo_set_state(sumo_handle_t h, const double* qpos, const double* qvel, cons
  * qacc (HOST float64 [E][nv]) plus per-env {ncon, nefc, newton iterations, dropped contacts} (HOST int32 [E][4]). */
 int sumo_debug_forward(sumo_handle_t h, const double* ctrl, double* qacc, int32_t* counts);
 /* device-side statistics accumulated since creation: forward calls, newton iterations, contacts, efc rows,
- * max ncon, max nefc, max newton iterations, dropped contacts (HOST float64 [8]). */
-int sumo_stats(sumo_handle_t h, double* out8);
+ * max ncon, max nefc, max newton iterations, dropped contacts, diverged env steps (HOST float64 [SUMO_NSTATS]). */
+#define SUMO_NSTATS 9
+int sumo_stats(sumo_handle_t h, double* out);
 /* per-phase shader-cycle totals (20 phases + 4 ad-hoc probe slots); all zero unless the library was built with
  * -DSUMO_PROFILE (HOST float64 [24]). */
 int sumo_profile(sumo_handle_t h, double* out24);

@@ -53,7 +53,7 @@ typedef struct {
   int* etype; /* 0 limit, 1 contact */
   double *Ma, *grad, *Mgrad, *search, *Mv, *Jv, *H, *tmpv;
   double *rkX[4], *rkF[4], *rkdX;
-  long n_forward, n_newton, n_contacts, n_efc, max_ncon, max_nefc, max_newton;
+  long n_forward, n_newton, n_contacts, n_efc, max_ncon, max_nefc, max_newton, n_diverged;
 } env_t;
 
 struct so_sim {
@@ -1017,6 +1017,15 @@ static float sumsq_f32(const float* a, int n) {
   return res;
 }
 
+/* MuJoCo's bad-value test (mj_checkPos / mj_checkVel / mj_checkAcc [EXT]: NaN or |x| > mjMAXVAL = 1e10 in qpos, qvel, qacc;
+ * the warning it raises becomes a MujocoException in the reference, mujoco-py/mujoco_py/builder.py:351-369). */
+static int state_is_bad(const so_sim* s, const env_t* d) {
+  const sumo_model_t* m = &s->m;
+  for (int i = 0; i < m->nq; i++) if (!(fabs(d->qpos[i]) <= 1e10)) return 1;
+  for (int i = 0; i < m->nv; i++) if (!(fabs(d->qvel[i]) <= 1e10) || !(fabs(d->warm[i]) <= 1e10)) return 1;
+  return 0;
+}
+
 static void env_step(const so_sim* s, env_t* d, const float* act, float* obs, double* info, uint8_t* done,
                      double* ep_r, double* ep_dr, int32_t* ep_l) {
   const sumo_model_t* m = &s->m;
@@ -1026,7 +1035,13 @@ static void env_step(const so_sim* s, env_t* d, const float* act, float* obs, do
   /* do_simulation: ctrl = concat(actions); frame_skip x mj_step */
   for (int a = 0; a < 2; a++)
     for (int i = 0; i < anu[a]; i++) d->ctrl[au[a] + i] = (double)act[a * s->act_stride + i];
-  for (int f = 0; f < m->frame_skip; f++) mj_step(s, d);
+  /* a state that fails the bad-value test before or after the frame_skip mj_steps ends the episode: zero rewards, info flag 4,
+   * auto-reset (the reference would have raised; MuJoCo itself tests in every mj_step, resets the data and warns) */
+  int diverged = state_is_bad(s, d);
+  if (!diverged) {
+    for (int f = 0; f < m->frame_skip; f++) mj_step(s, d);
+    diverged = state_is_bad(s, d);
+  }
   double ctrl_r[2];
   for (int a = 0; a < 2; a++) {
     after[a][0] = d->qpos[aq[a]]; after[a][1] = d->qpos[aq[a] + 1];
@@ -1061,10 +1076,16 @@ static void env_step(const so_sim* s, env_t* d, const float* act, float* obs, do
     I[0] = ctrl_r[a]; I[1] = lose; I[2] = win; I[3] = main_r; I[4] = move; I[5] = push; I[6] = shaping;
     I[7] = (double)flags;
   }
+  if (diverged) {
+    for (int k = 0; k < 2 * SO_INFO_STRIDE; k++) info[k] = 0.0;
+    info[7] = info[SO_INFO_STRIDE + 7] = 4.0;
+    dn = 1;
+    d->n_diverged++;
+  }
   /* wrapper bookkeeping (sumo_env.py:44-65, monitor.py:60-78): agent 0 only */
   d->ep_ret += info[3] + info[6];
   d->ep_dense += info[6];
-  if (dn && info[3] == -1000.0) { info[7] += 2.0; info[SO_INFO_STRIDE + 7] += 2.0; }
+  if (!diverged && dn && info[3] == -1000.0) { info[7] += 2.0; info[SO_INFO_STRIDE + 7] += 2.0; }
   done[0] = done[1] = (uint8_t)dn;
   if (dn) {
     *ep_r = d->ep_ret; *ep_dr = d->ep_dense; *ep_l = d->num_steps;
@@ -1255,7 +1276,7 @@ int so_get_array(so_sim* s, int e, const char* name, double* out, int cap) {
 }
 
 int so_stats(const so_sim* s, double* o) {
-  for (int k = 0; k < 8; k++) o[k] = 0;
+  for (int k = 0; k < 9; k++) o[k] = 0;
   for (int e = 0; e < s->N; e++) {
     const env_t* d = s->env + e;
     o[0] += d->n_forward; o[1] += d->n_newton; o[2] += d->n_contacts; o[3] += d->n_efc;
@@ -1263,6 +1284,7 @@ int so_stats(const so_sim* s, double* o) {
     if (d->max_nefc > o[5]) o[5] = d->max_nefc;
     if (d->max_newton > o[6]) o[6] = d->max_newton;
     o[7] += d->ncon_dropped;
+    o[8] += d->n_diverged;
   }
   return 0;
 }

@@ -230,10 +230,17 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
                     out = model.train(lrnow, cliprangenow, b_obs[mbflat], b_ret[mbflat], b_masks[mbflat], b_act[mbflat], b_val[mbflat],
                                       b_nlp[mbflat], None, weights[mbflat], st0[torch.from_numpy(mbenv).to(dev)], nsteps=nsteps)
                     mblossvals.append(torch.tensor([float(x) for x in out[:5]], dtype=torch.float64))
+        if not recurrent and hasattr(model, "begin_update"):
+            model.begin_update(b_obs, b_ret, b_act, b_val, b_nlp, weights)   # the update's batch, handed over once (model.py)
+        # minibatch steps per epoch (alg_ppo.py:378): with opponent-data reuse the ranks hold different numbers of rows, so they
+        # agree on the largest count and short ranks finish the epoch with empty minibatches (same collectives on every rank)
+        nmb_steps = -(-nsamp // nbatch_train)
+        if comm is not None and not model.equal_counts:
+            nmb_steps = sdist.agree_max(nmb_steps, comm, device=dev)
         for epoch in range(noptepochs if not recurrent else 0):
             inds = torch.randperm(nsamp, device=dev, generator=shuffle_gen).to(torch.int32)   # np.random.shuffle (:375), on the device
-            for ii, start in enumerate(range(0, nsamp, nbatch_train)):
-                mb = inds[start:start + nbatch_train]
+            for ii in range(nmb_steps):
+                mb = inds[ii * nbatch_train:(ii + 1) * nbatch_train]       # empty once this rank's rows are used up
                 # statistics stay on the device unless the KL early stop needs them now (alg_ppo.py:389-398)
                 out = model.train_indexed(lrnow, cliprangenow, b_obs, b_ret, b_act, b_val, b_nlp, weights, mb, int(mb.numel()),
                                           sync=kl_threshold is not None)
@@ -243,6 +250,8 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
                     break
             if early_stop:
                 break
+        if not recurrent and hasattr(model, "end_update"):
+            model.end_update()
         history["early_stop_info"].append(stop_info)
         if kl_threshold is None or recurrent:
             lossvals = torch.stack(mblossvals).mean(dim=0).cpu().numpy().astype(np.float64)

@@ -12,6 +12,7 @@ from . import build as _build
 
 INFO_STRIDE = 8
 NDIMS = 16
+NSTATS = 9
 _LIB = None
 
 
@@ -139,7 +140,7 @@ class Engine:
         return o
 
     def stats(self):
-        o = np.zeros(8)
+        o = np.zeros(NSTATS)
         _chk(lib().sumo_stats(self.h, _np(o)))
         return dict(forward=o[0], newton=o[1], contacts=o[2], efc=o[3], max_ncon=o[4], max_nefc=o[5],
-                    max_newton=o[6], dropped=o[7])
+                    max_newton=o[6], dropped=o[7], diverged=o[8])

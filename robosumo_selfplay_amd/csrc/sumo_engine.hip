@@ -417,6 +417,7 @@ struct Ctx {
 #endif
   // statistics accumulated over the launch
   int st_forward, st_newton, st_ncon, st_nefc, st_maxcon, st_maxefc, st_maxnewton, st_dropped, st_dense, st_cross;
+  int diverged;   // wave-uniform: the state failed MuJoCo's bad-value test (state_is_bad) during this env step
   int hcross;
 };
 
@@ -1788,6 +1789,18 @@ __device__ __forceinline__ void integrate_pos(C& c, double* qpos, const double* 
 }
 
 // frame_skip x mj_step with the RK4 stages flattened into one loop, so forward() has a single (inlined) call site.
+// MuJoCo's bad-value test (mj_checkPos / mj_checkVel / mj_checkAcc: NaN or |x| > mjMAXVAL = 1e10 in qpos, qvel, qacc; the
+// reference turns the resulting warning into a MujocoException, mujoco-py/mujoco_py/builder.py:351-369).  Wave-uniform result.
+template <class C>
+__device__ __forceinline__ int state_is_bad(C& c) {
+  const sumo_model_t& mdl = c.P->mdl;
+  const int lane = c.lane;
+  bool bad = false;
+  for (int i = lane; i < mdl.nq; i += WAVE) bad |= !(fabs(S(qpos)[i]) <= 1e10);   // NaN fails the comparison too
+  for (int i = lane; i < mdl.nv; i += WAVE) bad |= !(fabs(S(qvel)[i]) <= 1e10) || !(fabs(S(warm)[i]) <= 1e10);
+  return __builtin_amdgcn_ballot_w64(bad) != 0ull;
+}
+
 // RK4 tableau (MuJoCo): A = diag(1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6); the warm start saved at the end of a step is
 // the last stage's qacc.
 template <class C>
@@ -1953,6 +1966,7 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   __syncthreads();
   c.ncon = c.nlim = c.nefc = c.ndropped = c.use_prev = 0;
   c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = c.st_dense = c.st_cross = 0;
+  c.diverged = 0;
 #ifdef SUMO_PROFILE
   for (int k = 0; k < 24; k++) c.prof[k] = 0;
   c.tprev = clock64();
@@ -1985,8 +1999,9 @@ __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
     atomicMax(stats + 5, (unsigned long long)c.st_maxefc);
     atomicMax(stats + 6, (unsigned long long)c.st_maxnewton);
     atomicAdd(stats + 7, (unsigned long long)c.st_dropped);
+    if (c.diverged) atomicAdd(stats + 8, 1ull);
 #ifdef SUMO_PROFILE
-    for (int k = 0; k < 24; k++) atomicAdd(stats + 8 + k, c.prof[k]);
+    for (int k = 0; k < 24; k++) atomicAdd(stats + 16 + k, c.prof[k]);
 #endif
   }
 }
@@ -2045,7 +2060,12 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   if (lane < 2) { int qa = MI(agent_qposadr)[lane]; S(stash)[2 * lane] = S(qpos)[qa]; S(stash)[2 * lane + 1] = S(qpos)[qa + 1]; }
   SYNC();
   PROF(17);
-  mj_steps(c, mdl.frame_skip);
+  // bad-value guard, entry half: a state that already fails the test (host-imposed, or left by a launch that was cut short) is
+  // not integrated at all; the exit half sits in the epilogue.  Checked per env step, not per mj_step: a flag that lives across
+  // the twenty forward-dynamics evaluations costs the register budget more than stepping a lost state to the end (all loops
+  // of the pipeline are bounded; NaN comparisons fall through)
+  // (nothing stays live for it: a skipped state is still bad when the exit half looks)
+  if (!state_is_bad(c)) mj_steps(c, mdl.frame_skip);
   PROF(18);
   const float* act = a.actions + (size_t)e * 2 * a.act_stride;
   int* cnt = a.counters + 4 * e;
@@ -2089,9 +2109,22 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
     inf[g][0] = ctrl_r; inf[g][1] = lose; inf[g][2] = win; inf[g][3] = main_r; inf[g][4] = move; inf[g][5] = push;
     inf[g][6] = shaping; inf[g][7] = (double)flags;
   }
+  // per-env divergence guard: a state that failed the bad-value test (during the stepping or after its last mj_step) ends the
+  // episode with zero rewards and info flag 4; the auto-reset below replaces it, the engine counts it (sumo_stats[8])
+  const int diverged = state_is_bad(c);
+  c.diverged = diverged;
+  if (diverged) {
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+#pragma unroll
+      for (int k = 0; k < SUMO_INFO_STRIDE; k++) inf[g][k] = 0.0;
+      inf[g][7] = 4.0;
+    }
+    dn = 1;
+  }
   ep_ret += inf[0][3] + inf[0][6];
   ep_dense += inf[0][6];
-  if (dn && inf[0][3] == -1000.0) { inf[0][7] += 2.0; inf[1][7] += 2.0; }
+  if (!diverged && dn && inf[0][3] == -1000.0) { inf[0][7] += 2.0; inf[1][7] += 2.0; }
   if (lane == 0) {
     double* io = a.info + (size_t)e * 2 * SUMO_INFO_STRIDE;
 #pragma unroll
@@ -2682,8 +2715,8 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
   std::vector<uint64_t> seeds(N);
   for (size_t i = 0; i < N; i++) seeds[i] = i;
   HIPCHK(hipMemcpy(E->d_seeds, seeds.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc((void**)&E->d_stats, 32 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(E->d_stats, 0, 32 * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc((void**)&E->d_stats, 48 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(E->d_stats, 0, 48 * sizeof(unsigned long long)));
   {
     const char* sc = getenv("SUMO_SCHED");
     E->sched = !(sc && atoi(sc) == 0);
@@ -2892,18 +2925,18 @@ extern "C" int sumo_profile(sumo_handle_t E, double* out24) {  // cycle totals p
   if (!E || !out24) FAIL(-1, "bad arguments");
   HIPCHK(hipSetDevice(E->device));
   HIPCHK(hipDeviceSynchronize());
-  unsigned long long h[32];
+  unsigned long long h[48];
   HIPCHK(hipMemcpy(h, E->d_stats, sizeof h, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 24; i++) out24[i] = (double)h[8 + i];
+  for (int i = 0; i < 24; i++) out24[i] = (double)h[16 + i];
   return 0;
 }
 
-extern "C" int sumo_stats(sumo_handle_t E, double* out8) {
-  if (!E || !out8) FAIL(-1, "bad arguments");
+extern "C" int sumo_stats(sumo_handle_t E, double* out) {
+  if (!E || !out) FAIL(-1, "bad arguments");
   HIPCHK(hipSetDevice(E->device));
   HIPCHK(hipDeviceSynchronize());
-  unsigned long long h[8];
+  unsigned long long h[SUMO_NSTATS];
   HIPCHK(hipMemcpy(h, E->d_stats, sizeof h, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 8; i++) out8[i] = (double)h[i];
+  for (int i = 0; i < SUMO_NSTATS; i++) out[i] = (double)h[i];
   return 0;
 }

@@ -67,6 +67,18 @@ def allreduce_fused(grad_and_stats, group):
     return grad_and_stats
 
 
+def agree_max(value, group, device=None):
+    """MAX of a host integer over the ranks (e.g. the number of minibatch steps of an epoch when opponent-data reuse gives the
+    ranks different batch sizes: every rank must issue the same number of collectives)."""
+    import torch
+    import torch.distributed as dist
+    if group is None:
+        return int(value)
+    v = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+    return int(v.item())
+
+
 def assert_synced(params, group):
     """Counterpart of MpiAdamOptimizer.check_synced (mpi_adam_optimizer.py:54-67): every rank must hold identical weights."""
     import torch

@@ -109,21 +109,33 @@ class PPOModel(object):
                                 float(cliprange), self.ent_coef, self.vf_coef, self.grads.data_ptr(), self.stats.data_ptr(),
                                 log_ratio.data_ptr(), self.workspace.data_ptr(), st))
 
-    def _graph_step(self, lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n):
+    def begin_update(self, obs, returns, actions, values, neglogpacs, weights):
+        """Hand the batch arrays of ONE update to the model: they are copied (six device copies per update, not per step) into
+        buffers the model owns, so the captured step graph keeps valid pointers and is captured once per batch shape.  The
+        asynchronous ``train_indexed(..., sync=False)`` steps that follow gather their rows from these copies until
+        ``end_update()`` or the next ``begin_update``.  The hand-over is explicit on purpose: whether a caller's tensors still hold
+        the same content cannot be told from their addresses (a caller that refills its buffers in place, or frees and
+        re-allocates them, gets the same pointers back).  Without it ``train_indexed`` runs the eager launches on the arrays it
+        is given."""
+        t = self._t
+        if obs.stride(1) != 1:
+            raise ValueError("obs rows must have unit inner stride")
+        arrs = (obs, returns, actions, values, neglogpacs, weights)
+        shp = (tuple(obs.shape), obs.stride(0), tuple(weights.shape))
+        if self._static is None or self._static["shape"] != shp:
+            self._static = dict(shape=shp, bufs=[t.empty_like(x, memory_format=t.contiguous_format) for x in arrs])
+            self._graphs.clear()
+        for dst, x in zip(self._static["bufs"], arrs):
+            dst.copy_(x)
+        self._static["open"] = True
+
+    def end_update(self):
+        if self._static is not None:
+            self._static["open"] = False
+
+    def _graph_step(self, lr, cliprange, idx, n):
         t = self._t
         A = self.spec.ac_dim
-        # The batch arrays of an update are copied ONCE into buffers owned by the model (a device copy per update, not per
-        # step), so the captured graph keeps valid pointers across updates and is captured once per batch shape.
-        src = (obs.data_ptr(), returns.data_ptr(), actions.data_ptr(), values.data_ptr(), neglogpacs.data_ptr(), weights.data_ptr())
-        shp = (tuple(obs.shape), obs.stride(0))
-        if self._static is None or self._static["shape"] != shp:
-            self._static = dict(shape=shp, src=None, bufs=[t.empty_like(x, memory_format=t.contiguous_format)
-                                                           for x in (obs, returns, actions, values, neglogpacs, weights)])
-            self._graphs.clear()
-        if self._static["src"] != src:
-            for dst, x in zip(self._static["bufs"], (obs, returns, actions, values, neglogpacs, weights)):
-                dst.copy_(x)
-            self._static["src"] = src
         obs, returns, actions, values, neglogpacs, weights = self._static["bufs"]
         key = (int(n), float(cliprange))
         g = self._graphs.get(key)
@@ -178,12 +190,23 @@ class PPOModel(object):
         D, A = self.spec.ob_dim, self.spec.ac_dim
         if obs.stride(1) != 1:
             raise ValueError("obs rows must have unit inner stride")
-        if not sync and self.comm is None and idx is not None and self.use_graph:
-            out = self._graph_step(lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n)
+        if not sync and self.comm is None and idx is not None and self.use_graph and self._static is not None and self._static["open"]:
+            out = self._graph_step(lr, cliprange, idx, n)      # rows come from the begin_update() copies
             if out is not None:
                 return out
         st = t.cuda.current_stream(self.device).cuda_stream
         ip = ppo_capi.ptr(idx)
+        if n == 0:
+            # a rank whose shard ran out of rows (opponent-data reuse gives ranks different batch sizes) still takes part in
+            # both collectives of the step with an empty contribution, so every rank issues the same sequence of all-reduces
+            if self.comm is None or self.equal_counts:
+                raise ValueError("empty minibatch")
+            self.moments.zero_()
+            sdist.allreduce_moments(self.moments, self.comm)
+            self.grads.zero_()
+            sdist.allreduce_fused(self.grads, self.comm)
+            self.stats.copy_(self.grads[self.P:self.P + ppo_capi.NSTATS].to(t.float64))
+            return self._finish_step(lr, sync, t.empty(0, dtype=t.float32, device=self.device), st)
         # advantages: returns - values, normalised over the (global) minibatch (model.py:180-185)
         ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), st))
         sdist.allreduce_moments(self.moments, self.comm)
@@ -206,14 +229,19 @@ class PPOModel(object):
             self.grads[self.P:self.P + ppo_capi.NSTATS] = self.stats.to(t.float32)
             sdist.allreduce_fused(self.grads, self.comm)
             self.stats.copy_(self.grads[self.P:self.P + ppo_capi.NSTATS].to(t.float64))
+        return self._finish_step(lr, sync, log_ratio, st)
+
+    def _finish_step(self, lr, sync, log_ratio, st):
+        t = self._t
+        A = self.spec.ac_dim
         # entropy of the distribution the loss was evaluated with (before the parameter update), model.py:69
         logstd = self.params[self.P - 1 - policies.HIDDEN - A:self.P - 1 - policies.HIDDEN]
         entropy_t = (logstd.double() + 0.5 * np.log(2.0 * np.pi * np.e)).sum()
         self.t += 1
-        ppo_capi.chk(L.ppo_clip_adam(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.P,
-                                     self.t, float(lr), 0.9, 0.999, 1e-5,
-                                     float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0,
-                                     self.stats.data_ptr(), st))
+        ppo_capi.chk(ppo_capi.lib().ppo_clip_adam(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.P,
+                                                   self.t, float(lr), 0.9, 0.999, 1e-5,
+                                                   float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0,
+                                                   self.stats.data_ptr(), st))
         if not sync:
             st = self.stats
             return t.stack([st[0] / st[6], st[1] / st[6], entropy_t, st[3] / st[6], st[4] / st[6]])

@@ -204,6 +204,8 @@ class SumoVecEnv(VecEnv):
                     d["winner"] = True                                             # sumo.py:159
                 if flags & 2:
                     d["timeout"] = True                                            # sumo_env.py:62-65
+                if flags & 4:
+                    d["diverged"] = True       # bad-value guard (include/sumo_hip.h): the reference raises MujocoException there
                 per_agent.append(d)
             if done[e, 0]:                                                         # monitor.py:63-78 (agent 0 only)
                 per_agent[0]["episode"] = {"r": round(float(ep_r[e]), 6), "l": int(ep_l[e]), "t": now}

@@ -46,6 +46,20 @@ def _worker(rank, world, port, q):
         out["detects"] = False
     except AssertionError:
         out["detects"] = True
+    # opponent-data reuse: the ranks hold different numbers of rows (alg_ppo.py:331-335 filters per rank) -> they agree on the
+    # number of minibatch steps and the short rank finishes the epoch with empty contributions, so the collectives pair up
+    nbatch_train, nsamp = 64, (256 + 130 * rank)               # rank 0: 4 steps of its own, rank 1: ceil(386 / 64) = 7
+    steps = sdist.agree_max(-(-nsamp // nbatch_train), group)
+    out["steps"] = steps
+    seen = 0
+    for ii in range(steps):
+        rows = max(0, min(nbatch_train, nsamp - ii * nbatch_train))
+        mom = torch.tensor([0.0, 0.0, float(rows)], dtype=torch.float64)
+        sdist.allreduce_moments(mom, group)                     # would hang here if the ranks disagreed on the step count
+        fused = torch.full((10,), float(rows))
+        sdist.allreduce_fused(fused, group)
+        seen += int(mom[2].item())
+    out["rows_seen"] = seen
     q.put((rank, out))
     torch.distributed.destroy_process_group()
 
@@ -67,6 +81,7 @@ def test_two_rank_gloo_collectives():
     for r in range(world):
         o = res[r]
         assert o["params_ok"] and o["synced"] and o["fused_ok"] and o["detects"]
+        assert o["steps"] == 7 and o["rows_seen"] == 256 + 386       # every row of both ranks counted once, same step count
         s, s2, n = o["mom"]
         assert n == all_adv.size and s / n == pytest.approx(all_adv.mean()) and np.sqrt(s2 / n - (s / n) ** 2) == pytest.approx(all_adv.std())
 

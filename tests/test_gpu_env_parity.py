@@ -303,3 +303,33 @@ def test_env_groups_are_transparent():
     assert outs[0][1]["forward"] == outs[1][1]["forward"] and outs[0][1]["newton"] == outs[1][1]["newton"]
     with pytest.raises(ValueError):
         SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=10, groups=4)
+
+
+@pytest.mark.parametrize("env_id", ["RoboSumo-Ant-vs-Ant-v0", "RoboSumo-Spider-vs-Spider-v0"])
+def test_divergence_guard_parity(env_id):
+    """Bad-value guard (include/sumo_hip.h, info flag 4; reference: mujoco-py/mujoco_py/builder.py:351-369 raises there): states
+    poisoned through sumo_set_state with NaN / Inf / |x| > 1e10 end their episode in the HIP engine exactly as in the oracle --
+    done, zero rewards, flag, finite reset observation, counter -- and leave every other env bit-identical."""
+    N = 16
+    p = Pair(env_id, N)
+    p.reset()
+    rng = np.random.default_rng(4)
+    acts = [rng.standard_normal((N, 2, p.eng.act_stride)).astype(np.float32) for _ in range(4)]
+    for a in acts[:2]:
+        p.step(a)
+    q, v, w, c = p.ora.get_state()
+    q[1, 5] = np.nan; v[4, 3] = np.inf; v[7, p.eng.nv - 1] = -3e10; w[9, 0] = np.nan; q[12, 2] = 2e10
+    bad = [1, 4, 7, 9, 12]
+    p.ora.set_state(q, v, w, c)
+    p.eng.set_state(q, v, w, c)
+    g, o = p.step(acts[2])
+    assert np.array_equal(g[2], o[2]) and g[2][bad].all()
+    assert np.all(g[1][bad][:, :, :7] == 0) and np.all(g[1][bad][:, :, 7] == 4) and np.array_equal(g[1][bad], o[1][bad])
+    assert np.isfinite(g[0]).all() and np.array_equal(g[0], o[0])                      # observations (reset ones for the bad envs) bit-equal
+    ok = [e for e in range(N) if e not in bad]
+    assert relerr(g[1][ok], o[1][ok]) < (REL if "Ant" in env_id else 1e-6)
+    assert np.array_equal(g[5], o[5]) and np.isfinite(g[3]).all()
+    assert p.eng.stats()["diverged"] == len(bad) == p.ora.stats()["diverged"]
+    g, o = p.step(acts[3])                                                               # fresh episodes carry on, still in step with the oracle
+    assert np.array_equal(g[0], o[0]) and np.array_equal(g[2], o[2]) and np.isfinite(g[1]).all()
+    assert p.eng.stats()["diverged"] == len(bad)

@@ -314,30 +314,43 @@ def test_learn_opponent_modes_and_opponent_data(tmp_path):
 
 
 def test_graph_replay_matches_eager_steps():
-    """The HIP-graph path of train_indexed (asynchronous, single GPU) replays exactly the eager launches."""
+    """The HIP-graph path of train_indexed (asynchronous, single GPU, after begin_update) replays exactly the eager launches --
+    also when the caller refills the SAME tensors in place between two updates (the batch is handed over explicitly by
+    begin_update; nothing is inferred from addresses)."""
     rng = np.random.default_rng(3)
     D, A, nb, n = 121, 8, 4096, 512
-    obs = torch.from_numpy(rng.standard_normal((nb, D)).astype(np.float32)).to(DEV)
-    act = torch.from_numpy(rng.standard_normal((nb, A)).astype(np.float32)).to(DEV)
-    ret = torch.from_numpy(rng.standard_normal(nb).astype(np.float32)).to(DEV)
-    val = torch.from_numpy(rng.standard_normal(nb).astype(np.float32)).to(DEV)
+    mk = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(DEV)
+    batches = [(mk(nb, D), mk(nb, A), mk(nb), mk(nb)) for _ in range(2)]
     w = torch.ones(nb, dtype=torch.float32, device=DEV)
     res = []
     for use_graph in (False, True):
         m = _model(D, A, seed=5)
         m.use_graph = use_graph
-        nlp = m.act_model.action_probability(obs, given_action=act) + 0.05
+        obs, act, ret, val = (x.clone() for x in batches[0])         # persistent caller buffers, overwritten per update
         outs = []
         r2 = np.random.default_rng(9)
-        for k in range(6):
-            idx = torch.from_numpy(r2.permutation(nb)[:n].astype(np.int32)).to(DEV)
-            outs.append(m.train_indexed(1e-3, 0.2, obs, ret, act, val, nlp, w, idx, n, sync=False))
+        for upd in range(2):
+            for dst, src in zip((obs, act, ret, val), batches[upd]):
+                dst.copy_(src)                                            # same addresses, new content
+            nlp = m.act_model.action_probability(obs, given_action=act) + 0.05
+            if use_graph:
+                m.begin_update(obs, ret, act, val, nlp, w)
+            for k in range(4):
+                idx = torch.from_numpy(r2.permutation(nb)[:n].astype(np.int32)).to(DEV)
+                outs.append(m.train_indexed(1e-3, 0.2, obs, ret, act, val, nlp, w, idx, n, sync=False))
+            m.end_update()
         torch.cuda.synchronize()
         assert (len(m._graphs) == 1) == use_graph
         res.append((m.params.clone(), torch.stack(outs).cpu().numpy(), m.t))
-    assert res[0][2] == res[1][2] == 6
+    assert res[0][2] == res[1][2] == 8
     assert torch.equal(res[0][0], res[1][0])
     assert np.array_equal(res[0][1], res[1][1])
+    # without a hand-over the asynchronous step stays on the eager launches (never on a stale private copy)
+    m = _model(D, A, seed=5)
+    obs, act, ret, val = batches[0]
+    nlp = m.act_model.action_probability(obs, given_action=act) + 0.05
+    m.train_indexed(1e-3, 0.2, obs, ret, act, val, nlp, w, torch.arange(n, dtype=torch.int32, device=DEV), n, sync=False)
+    assert len(m._graphs) == 0
 
 
 @pytest.mark.parametrize("ob,ac,n", [(121, 8, 100), (209, 16, 37)])

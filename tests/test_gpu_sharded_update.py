@@ -78,6 +78,106 @@ def test_two_shards_match_single_process():
     assert np.allclose(res[1][1], ref_st, rtol=1e-3, atol=1e-5)
 
 
+def _uneven_worker(rank, world, port, q):
+    """Opponent-data reuse shape (alg_ppo.py:331-335): rank 0 holds 1536 rows, rank 1 512; minibatches of 512 -> rank 1 runs out
+    after one step and joins the remaining two with empty minibatches (model.train_indexed n == 0)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from robosumo_selfplay_amd import dist as sdist, model as model_mod, policies
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = dist.group.WORLD
+    np.random.seed(3)
+    m = model_mod.PPOModel(policy=policies.PolicySpec(OB, AC, value_network="copy", activation="relu"), ent_coef=0.01, vf_coef=0.5,
+                           max_grad_norm=0.5, comm=comm)
+    m.equal_counts = False
+    sdist.broadcast_params(m.params, comm)
+    lo, hi = (0, 1536) if rank == 0 else (1536, 2048)
+    obs, act, ret, val, old = (torch.as_tensor(x[lo:hi]).cuda() for x in _batch())
+    w = torch.ones(hi - lo, dtype=torch.float32, device="cuda")
+    steps = sdist.agree_max(-(-(hi - lo) // 512), comm, device=torch.device("cuda", 0))
+    idx = torch.arange(hi - lo, dtype=torch.int32, device="cuda")
+    for ii in range(steps):
+        mb = idx[ii * 512:(ii + 1) * 512]
+        st = m.train_indexed(1e-3, 0.2, obs, ret, act, val, old, w, mb, int(mb.numel()))
+    sdist.assert_synced(m.params, comm)
+    q.put((rank, m.params.cpu().numpy(), steps, np.array(st[:5], dtype=np.float64)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_uneven_shards_keep_collectives_paired():
+    import torch
+    import torch.multiprocessing as mp
+    from robosumo_selfplay_amd import model as model_mod, policies
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, p, steps, st = q.get(timeout=300)
+        res[r] = (p, steps, st)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 3
+    assert np.array_equal(res[0][0], res[1][0])
+    # single process, same global minibatches: step 0 = rows [0,512) + [1536,2048), steps 1,2 = rows [512,1024), [1024,1536)
+    np.random.seed(3)
+    m = model_mod.PPOModel(policy=policies.PolicySpec(OB, AC, value_network="copy", activation="relu"), ent_coef=0.01, vf_coef=0.5,
+                           max_grad_norm=0.5)
+    obs, act, ret, val, old = (torch.as_tensor(x).cuda() for x in _batch())
+    w = torch.ones(N, dtype=torch.float32, device="cuda")
+    for rows in (list(range(0, 512)) + list(range(1536, 2048)), list(range(512, 1024)), list(range(1024, 1536))):
+        mb = torch.tensor(rows, dtype=torch.int32, device="cuda")
+        st = m.train_indexed(1e-3, 0.2, obs, ret, act, val, old, w, mb, len(rows))
+    assert np.allclose(res[0][0], m.params.cpu().numpy(), rtol=0, atol=2e-5)
+    assert np.allclose(res[1][2], np.array(st[:5], dtype=np.float64), rtol=1e-3, atol=1e-5)   # the empty rank reports the global means too
+
+
+def _rccl_worker(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from robosumo_selfplay_amd import dist as sdist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))      # the call bench.py / run.py make
+    comm = dist.group.WORLD
+    p, st = _train(comm, 0, N)
+    buf = torch.arange(24529 + 8, dtype=torch.float32, device="cuda")
+    sdist.allreduce_fused(buf, comm)
+    ok = bool(torch.equal(buf.cpu(), torch.arange(24529 + 8, dtype=torch.float32))) and sdist.agree_max(5, comm, device=torch.device("cuda", 0)) == 5
+    q.put((p, st, ok, dist.get_backend(comm)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_rccl_process_group_world_size_one():
+    """The RCCL ('nccl') initialisation and collective path of dist.py / bench.py executes on hardware: one rank, real
+    all-reduces of the fused gradient buffer and the advantage moments, same update as without a communicator."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_worker, args=(port, q))
+    pr.start()
+    p, st, ok, backend = q.get(timeout=300)
+    pr.join(timeout=120)
+    assert pr.exitcode == 0 and ok and backend == "nccl"
+    ref_p, ref_st = _train(None, 0, N)
+    assert np.allclose(p, ref_p, rtol=0, atol=2e-6) and np.allclose(st, ref_st, rtol=1e-4, atol=1e-6)
+
+
 # ---- the same for the recurrent model: each rank back-propagates through its own env sequences -----------------------
 LT, LN, LD, LA, LH = 6, 16, 17, 3, 64
 

@@ -278,3 +278,40 @@ def test_maxcon_cap_drops_in_order(spider_model, oracle_lib):
     capped.forward(0, np.zeros(spider_model.nu))
     cc = capped.array("contacts").reshape(-1, 9)
     assert len(cc) == ncon - 2 and np.array_equal(cc, full[:ncon - 2]) and capped.array("counts")[2] == 2
+
+
+@pytest.mark.parametrize("poison", ["nan_qpos", "inf_qvel", "huge_qvel", "nan_warm"])
+def test_divergence_guard_ends_the_episode(ant_model, oracle_lib, poison):
+    """Bad-value guard (MuJoCo mj_checkPos/Vel/Acc: NaN or |x| > 1e10; the reference's mujoco-py turns it into a
+    MujocoException, mujoco-py/mujoco_py/builder.py:351-369): the poisoned env reports done, zero rewards, info flag 4, a finite
+    reset observation and is counted; its neighbours are untouched."""
+    N = 4
+    sim = oracle_lib.OracleSim(ant_model, N)
+    ref = oracle_lib.OracleSim(ant_model, N)
+    seeds = np.arange(N) + 21
+    sim.reset(seeds=seeds); ref.reset(seeds=seeds)
+    a = np.random.default_rng(0).standard_normal((N, 2, sim.act_stride)).astype(np.float32)
+    for _ in range(3):
+        sim.step(a, nthreads=2); ref.step(a, nthreads=2)
+    q, v, w, c = sim.get_state()
+    if poison == "nan_qpos":
+        q[1, 5] = np.nan
+    elif poison == "inf_qvel":
+        v[1, 3] = np.inf
+    elif poison == "huge_qvel":
+        v[1, 20] = -3e10
+    else:
+        w[1, 0] = np.nan
+    sim.set_state(q, v, w, c)
+    obs, info, done, ep_r, ep_dr, ep_l = sim.step(a, nthreads=2)
+    robs, rinfo, rdone, *_ = ref.step(a, nthreads=2)
+    assert done[1].all() and np.all(info[1, :, :7] == 0) and np.all(info[1, :, 7] == 4)
+    assert np.isfinite(obs).all() and obs[1, 0, -1] == -1.0 and ep_l[1] == 4           # reset observation, episode length reported
+    assert np.isfinite(ep_r).all()
+    keep = [0, 2, 3]
+    assert np.array_equal(obs[keep], robs[keep]) and np.array_equal(info[keep], rinfo[keep]) and np.array_equal(done[keep], rdone[keep])
+    assert sim.stats()["diverged"] == 1 and ref.stats()["diverged"] == 0
+    q2, v2, w2, c2 = sim.get_state()
+    assert np.isfinite(q2).all() and np.isfinite(v2).all() and np.isfinite(w2).all() and c2[1, 0] == 0
+    obs, info, done, *_ = sim.step(a, nthreads=2)                                       # and it carries on like any fresh episode
+    assert np.isfinite(obs).all() and np.isfinite(info).all() and sim.stats()["diverged"] == 1

@@ -12,6 +12,8 @@ for graph in (True, False):
     PPOModel.use_graph = graph
     m = PPOModel(policy=policies.PolicySpec(D, A, value_network="copy", activation="relu"))
     nlp = m.act_model.action_probability(obs, given_action=act)
+    if graph:
+        m.begin_update(obs, ret, act, val, nlp, w)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     m.train_indexed(3e-4, 0.2, obs, ret, act, val, nlp, w, torch.arange(n, device=dev, dtype=torch.int32), n, sync=False)
     torch.cuda.synchronize(); print('graph %s: first step (capture) %.1f ms' % (graph, (time.perf_counter() - t0) * 1e3), flush=True)
