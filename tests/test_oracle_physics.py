@@ -315,3 +315,262 @@ def test_divergence_guard_ends_the_episode(ant_model, oracle_lib, poison):
     assert np.isfinite(q2).all() and np.isfinite(v2).all() and np.isfinite(w2).all() and c2[1, 0] == 0
     obs, info, done, *_ = sim.step(a, nthreads=2)                                       # and it carries on like any fresh episode
     assert np.isfinite(obs).all() and np.isfinite(info).all() and sim.stats()["diverged"] == 1
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SURVEY.md §7 S1 known answers that exercise the velocity-dependent terms (rne_bias / cdof_dot), the RK4 integrator and the
+# constraint solver independently of both implementations.  All observables are computed in numpy from the body Jacobians of
+# mjcf.mass_matrix_np (a different formulation from the oracle's composite-rigid-body / RNE passes).
+# ----------------------------------------------------------------------------------------------------------------------
+def _conservative_copy(model, timestep=None):
+    """Test-only model edit: no joint damping, no joint limits (so free flight is a conservative system)."""
+    import copy
+    m = copy.deepcopy(model)
+    m.tables["dof_damping"] = np.zeros_like(m.tables["dof_damping"])
+    m.tables["jnt_limited"] = np.zeros_like(m.tables["jnt_limited"])
+    # ... and no collisions between an agent's own geoms (limbs swinging past their ranges would touch the torso)
+    b, root = m.geom_bodyid, m.body_rootid
+    keep = np.array([b[g1] == 0 or b[g2] == 0 or root[b[g1]] != root[b[g2]] for g1, g2 in zip(m.pair_geom1, m.pair_geom2)])
+    for k in [k for k in m.tables if k.startswith("pair_")]:
+        m.tables[k] = m.tables[k][keep]
+    m.npair = int(keep.sum())
+    if timestep is not None:
+        opt = m.tables["opt"].copy(); opt[0] = timestep; m.tables["opt"] = opt
+    return m
+
+
+def _agent_observables(m, q, v):
+    """Per agent: total energy (kinetic incl. armature + potential) and angular momentum about its own centre of mass (world)."""
+    M, jacp, jacr = mjcf.mass_matrix_np(m, q)
+    xpos, xquat, _, _ = mjcf.kinematics_np(m, q)
+    out = []
+    for a in range(2):
+        b0, nb = int(m.agent_bodyadr[a]), int(m.agent_nbody[a])
+        d0, nd = int(m.agent_dofadr[a]), int(m.agent_nv[a])
+        bodies = range(b0, b0 + nb)
+        mass = np.array([m.body_mass[b] for b in bodies])
+        xi = np.array([xpos[b] + mjcf.quat2mat(xquat[b]) @ m.body_ipos[b] for b in bodies])
+        com = (mass[:, None] * xi).sum(0) / mass.sum()
+        L = np.zeros(3)
+        for k, b in enumerate(bodies):
+            R = mjcf.quat2mat(mjcf.quat_mul(xquat[b], m.body_iquat[b]))
+            Iw = R @ np.diag(m.body_inertia[b]) @ R.T
+            L += Iw @ (jacr[b] @ v) + mass[k] * np.cross(xi[k] - com, jacp[b] @ v)
+        va = v[d0:d0 + nd]
+        ke = 0.5 * va @ M[d0:d0 + nd, d0:d0 + nd] @ va
+        pe = G * (mass * xi[:, 2]).sum()
+        out.append((ke + pe, L))
+    return out
+
+
+def _tumbling_state(m, rng, spin=3.0, joint_rate=4.0):
+    q = m.qpos0.copy()
+    v = np.zeros(m.nv)
+    for a in range(2):
+        qa, da, nqa, nva = int(m.agent_qposadr[a]), int(m.agent_dofadr[a]), int(m.agent_nq[a]), int(m.agent_nv[a])
+        q[qa:qa + 3] = [(-1) ** a * 6.0, 0.0, 40.0]                   # far from the floor and from each other for the whole flight
+        quat = rng.standard_normal(4); q[qa + 3:qa + 7] = quat / np.linalg.norm(quat)
+        for k in range(nqa - 7):
+            lo, hi = m.jnt_range[int(np.where(m.jnt_qposadr == qa + 7 + k)[0][0])]
+            q[qa + 7 + k] = 0.5 * (lo + hi)
+        v[da:da + 3] = rng.standard_normal(3)
+        v[da + 3:da + 6] = rng.standard_normal(3) * spin
+        v[da + 6:da + nva] = rng.standard_normal(nva - 6) * joint_rate
+    return q, v
+
+
+@pytest.mark.parametrize("which", ["ant", "spider"])
+def test_free_flight_conserves_energy_and_angular_momentum(ant_model, spider_model, oracle_lib, which):
+    """200 RK4 steps of tumbling free flight with every joint moving (no damping, no limits, gravity on): each agent's total
+    energy and its angular momentum about its own centre of mass stay constant to the integrator's accuracy.  These are the
+    quantities that depend on the Coriolis / centrifugal terms (the oracle's rne_bias and cdof_dot passes); a sign or frame
+    error there shows up as O(1) drift within a few steps."""
+    m = _conservative_copy(ant_model if which == "ant" else spider_model)
+    sim = oracle_lib.OracleSim(m, 1)
+    q, v = _tumbling_state(m, np.random.default_rng(5))
+    sim.set_state(q[None], v[None], np.zeros((1, m.nv)), np.zeros((1, 2), np.int32))
+    obs0 = _agent_observables(m, q, v)
+    worst_e = worst_l = 0.0
+    for chunk in range(4):
+        sim.mj_step(0, np.zeros(m.nu), 50)
+        assert sim.array("counts")[0] == 0 and sim.array("counts")[1] == 0      # really free flight: no contact, no limit row
+        q1, v1, _, _ = sim.get_state()
+        for (e0, L0), (e1, L1) in zip(obs0, _agent_observables(m, q1[0], v1[0])):
+            ke_scale = abs(e0 - G * 40.0 * m.body_mass[1:1 + int(m.agent_nbody[0])].sum()) + 1.0
+            worst_e = max(worst_e, abs(e1 - e0) / ke_scale)
+            worst_l = max(worst_l, np.abs(L1 - L0).max() / (np.abs(L0).max() + 1e-3))
+    assert worst_e < 3e-3 and worst_l < 6e-3, (worst_e, worst_l)     # second-order drift at h = 0.01 (see the step-halving test below)
+
+
+def test_free_flight_drift_shrinks_with_the_step(ant_model, oracle_lib):
+    """Halving the time step divides the energy / angular-momentum drift over the same physical time by ~4.  MuJoCo's
+    mj_RungeKutta applies the classical RK4 tableau but moves positions with mj_integratePos from the step's base point
+    (SURVEY App. A.12 [EXT]); on the quaternion part that is a Lie-group Runge-Kutta without the dexp^-1 correction, which
+    is second order -- the restatement shows exactly that order (ratios 3.99-4.09 measured), and every drift goes to zero
+    with the step, i.e. stage states, quaternion update and bias forces are mutually consistent."""
+    drifts = []
+    for h, n in ((0.02, 50), (0.01, 100), (0.005, 200)):
+        m = _conservative_copy(ant_model, timestep=h)
+        sim = oracle_lib.OracleSim(m, 1)
+        q, v = _tumbling_state(m, np.random.default_rng(8), spin=4.0, joint_rate=6.0)
+        sim.set_state(q[None], v[None], np.zeros((1, m.nv)), np.zeros((1, 2), np.int32))
+        o0 = _agent_observables(m, q, v)
+        sim.mj_step(0, np.zeros(m.nu), n)
+        q1, v1, _, _ = sim.get_state()
+        o1 = _agent_observables(m, q1[0], v1[0])
+        drifts.append((abs(o1[0][0] - o0[0][0]), np.abs(o1[0][1] - o0[0][1]).max()))
+    for k in range(2):
+        re, rl = drifts[k][0] / drifts[k + 1][0], drifts[k][1] / drifts[k + 1][1]
+        assert 3.0 < re < 5.0 and 3.0 < rl < 5.0, (drifts, re, rl)
+
+
+def _advance_np(m, q, v, eps):
+    """q (+) eps * v on the configuration manifold, in numpy (free joints: world-frame translation, body-frame rotation)."""
+    q = q.copy()
+    for j in range(m.njnt):
+        qa, da = int(m.jnt_qposadr[j]), int(m.jnt_dofadr[j])
+        if m.jnt_type[j] == mjcf.JNT_FREE:
+            q[qa:qa + 3] += eps * v[da:da + 3]
+            w = eps * v[da + 3:da + 6]
+            ang = np.linalg.norm(w)
+            dq = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * w / ang]) if ang > 0 else np.array([1.0, 0, 0, 0])
+            q[qa + 3:qa + 7] = mjcf.quat_mul(q[qa + 3:qa + 7], dq)
+        else:
+            q[qa] += eps * v[da]
+    return q
+
+
+@pytest.mark.parametrize("which", ["ant", "spider"])
+def test_free_flight_acceleration_keeps_invariants_stationary(ant_model, spider_model, oracle_lib, which):
+    """Integrator-independent form of the conservation test: with the oracle's qacc, d/dt of each agent's total energy and of
+    its angular momentum about its centre of mass vanish (central differences of the numpy observables along (v, qacc)).
+    Pins the velocity-dependent bias forces (Coriolis, centrifugal, gyroscopic: rne_bias / cdof_dot) to ~1e-8 of their size."""
+    m = _conservative_copy(ant_model if which == "ant" else spider_model)
+    sim = oracle_lib.OracleSim(m, 1)
+    rng = np.random.default_rng(12)
+    for trial in range(3):
+        q, v = _tumbling_state(m, rng, spin=5.0, joint_rate=7.0)
+        sim.set_state(q[None], v[None], np.zeros((1, m.nv)), np.zeros((1, 2), np.int32))
+        sim.forward(0, np.zeros(m.nu))
+        assert sim.array("counts")[0] == 0 and sim.array("counts")[1] == 0
+        a = sim.array("qacc")
+        bias = sim.array("qfrc_bias")
+        eps = 1e-5
+        plus = _agent_observables(m, _advance_np(m, q, v, eps), v + eps * a)
+        minus = _agent_observables(m, _advance_np(m, q, v, -eps), v - eps * a)
+        M, _, _ = mjcf.mass_matrix_np(m, q)
+        for ag in range(2):
+            d0, nd = int(m.agent_dofadr[ag]), int(m.agent_nv[ag])
+            power_scale = np.abs(v[d0:d0 + nd] * bias[d0:d0 + nd]).sum() + 1.0            # size of the terms that must cancel
+            torque_scale = np.abs(bias[d0 + 3:d0 + 6]).max() + 1.0
+            dE = (plus[ag][0] - minus[ag][0]) / (2 * eps)
+            dL = (plus[ag][1] - minus[ag][1]) / (2 * eps)
+            assert abs(dE) < 1e-6 * power_scale, (trial, ag, dE, power_scale)
+            assert np.abs(dL).max() < 1e-6 * torque_scale, (trial, ag, dL, torque_scale)
+        assert np.abs(bias).max() > 1.0                                                    # the terms under test are not trivially zero
+
+
+def test_newton_solution_satisfies_kkt(ant_model, spider_model, oracle_lib):
+    """The constrained acceleration the oracle's Newton solver returns is the optimum of MuJoCo's convex problem
+    (SURVEY App. A.10-11): min_a 1/2 (a - a_smooth)' M (a - a_smooth) + sum_i s_i(J_i a - aref_i), s_i(x) = x^2 / (2 R_i) for x < 0
+    else 0 (limit and pyramidal contact rows).  Checked in numpy on >= 50 contact-rich states, with M from the independent
+    Jacobian formulation: stationarity M (a - a_smooth) = J' f, dual feasibility f >= 0, f_i = max(0, -jar_i) / R_i."""
+    checked = most = 0
+    worst = 0.0
+    for m, N, steps in ((ant_model, 64, 50), (spider_model, 32, 40)):
+        sim = oracle_lib.OracleSim(m, N)
+        sim.reset(seeds=np.arange(N) + 77)
+        rng = np.random.default_rng(2)
+        for t in range(steps):      # thrash, then let most of them come down again (small actions) so that feet and bodies touch
+            a = rng.standard_normal((N, 2, sim.act_stride)).astype(np.float32) * (1.0 if t < steps // 2 else 0.2)
+            sim.step(a, nthreads=4)
+        qs, vs, _, _ = sim.get_state()
+        for e in range(N):
+            ctrl = np.clip(rng.standard_normal(m.nu), -1, 1)
+            sim.forward(e, ctrl)
+            ncon, nefc = int(sim.array("counts", e)[0]), int(sim.array("counts", e)[1])
+            if ncon < 2:
+                continue
+            J = sim.array("efc_J", e).reshape(nefc, m.nv)
+            f, R, jar = sim.array("efc_force", e), sim.array("efc_R", e), sim.array("efc_jar", e)
+            aref = sim.array("efc_aref", e)
+            qacc, qs_ = sim.array("qacc", e), sim.array("qacc_smooth", e)
+            M, _, _ = mjcf.mass_matrix_np(m, qs[e])
+            assert np.allclose(jar, J @ qacc - aref, atol=1e-9 * (1 + np.abs(aref).max()))
+            assert np.all(f >= 0) and np.all(R > 0)
+            assert np.allclose(f, np.maximum(0.0, -jar) / R, rtol=1e-12, atol=1e-12)            # complementarity built into the force law
+            res = M @ (qacc - qs_) - J.T @ f
+            scale = np.abs(M @ (qacc - qs_)).max() + np.abs(J.T @ f).max() + 1.0
+            worst = max(worst, np.abs(res).max() / scale)
+            checked += 1
+            most = max(most, ncon)
+    assert checked >= 50 and most >= 8, (checked, most)
+    assert worst < 1e-7, worst                 # solver tolerance 1e-8 on the scaled gradient norm (opt[4])
+
+
+@pytest.mark.parametrize("armature", [0.0, 1.0])
+def test_centrifugal_pendulum_period(ant_model, oracle_lib, armature):
+    """Pendulum known answer for ONE hinge.  The scene has no world-fixed hinge, so the pendulum is a centrifugal one: the torso
+    (test-only edit: 10^6 x heavier, every other joint frozen by a 10^9 armature, no gravity / damping / limits) spins at Omega
+    about its vertical axis; hip_1's axis is parallel to it at distance r, so the leg swings about the radial direction with
+    omega^2 = Omega^2 m r d / (I_hinge + armature)  (m, d: mass and centre-of-mass distance of the swinging limb, I_hinge its
+    inertia about the hinge axis -- all computed here in numpy).  Only the centrifugal / Coriolis bias terms drive this motion
+    and the armature enters as MuJoCo defines it (joint-space diagonal only), so the period pins both."""
+    import copy
+    m = _conservative_copy(ant_model)
+    opt = m.tables["opt"].copy(); opt[1:4] = 0.0; m.tables["opt"] = opt
+    arm = np.full(m.nv, 1e9); arm[:6] = 0.0; arm[14:20] = 0.0                    # free joints untouched, every hinge frozen ...
+    hip = m.joint_names.index("ant0/hip_1")
+    hd, hq = int(m.jnt_dofadr[hip]), int(m.jnt_qposadr[hip])
+    arm[hd] = armature                                                            # ... except the pendulum's
+    m.tables["dof_armature"] = arm
+    torso = int(m.agent_torso[0])
+    mass = m.tables["body_mass"].copy(); mass[torso] *= 1e6; m.tables["body_mass"] = mass
+    sub = mass.copy()                                                             # the derived table that goes with body_mass
+    for b in range(m.nbody - 1, 0, -1):
+        sub[int(m.body_parentid[b])] += sub[b]
+    m.tables["body_subtreemass"] = sub
+    inert = m.tables["body_inertia"].copy(); inert[torso] *= 1e6; m.tables["body_inertia"] = inert
+    q = m.qpos0.copy()
+    q[0:3] = [0.0, 0.0, 40.0]; q[3:7] = [1, 0, 0, 0]
+    q[15:18] = [30.0, 0.0, 40.0]
+    for j in range(m.njnt):
+        if m.jnt_type[j] != mjcf.JNT_FREE:
+            q[int(m.jnt_qposadr[j])] = 0.5 * (m.jnt_range[j][0] + m.jnt_range[j][1])
+    q[hq] = 0.0
+    # the swinging limb: bodies hanging below hip_1
+    limb = [b for b in range(m.nbody) if b == int(m.jnt_bodyid[hip]) or int(m.body_parentid[b]) == int(m.jnt_bodyid[hip])]
+    xpos, xquat, xanchor, xaxis = mjcf.kinematics_np(m, q)
+    assert abs(abs(xaxis[hip][2]) - 1.0) < 1e-12                                  # hinge axis parallel to the spin axis
+    anchor = xanchor[hip][:2] - xpos[torso][:2]
+    mb = np.array([m.body_mass[b] for b in limb])
+    xi = np.array([xpos[b] + mjcf.quat2mat(xquat[b]) @ m.body_ipos[b] for b in limb])
+    com = (mb[:, None] * xi).sum(0) / mb.sum()
+    rel = com[:2] - xanchor[hip][:2]
+    r, d = np.linalg.norm(anchor), np.linalg.norm(rel)
+    assert abs(np.cross(anchor / r, rel / d)) < 1e-9                              # theta = 0 is the radial equilibrium
+    I_h = 0.0
+    for k, b in enumerate(limb):
+        R = mjcf.quat2mat(mjcf.quat_mul(xquat[b], m.body_iquat[b]))
+        I_h += (R @ np.diag(m.body_inertia[b]) @ R.T)[2, 2] + mb[k] * np.sum((xi[k][:2] - xanchor[hip][:2]) ** 2)
+    Omega = 5.0
+    omega = Omega * np.sqrt(mb.sum() * r * d / (I_h + armature))
+    theta0 = 0.02
+    q[hq] = theta0
+    v = np.zeros(m.nv); v[5] = Omega
+    sim = oracle_lib.OracleSim(m, 1)
+    sim.set_state(q[None], v[None], np.zeros((1, m.nv)), np.zeros((1, 2), np.int32))
+    period = 2 * np.pi / omega
+    h = float(m.opt[0])
+    n = int(2.6 * period / h)
+    th = np.empty(n)
+    for k in range(n):
+        sim.mj_step(0, np.zeros(m.nu), 1)
+        th[k] = sim.get_state()[0][0, hq]
+    assert sim.array("counts")[0] == 0
+    assert abs(th).max() < theta0 * 1.001 and th.min() < -0.99 * theta0           # a clean oscillation about the radial direction
+    up = [k for k in range(n - 1) if th[k] < 0 <= th[k + 1]]                      # upward zero crossings, linearly interpolated
+    t_cross = [(k + 1 + th[k] / (th[k] - th[k + 1])) * h for k in up]
+    assert len(t_cross) >= 2
+    measured = t_cross[1] - t_cross[0]
+    assert measured == pytest.approx(period * (1 + theta0 ** 2 / 16), rel=2e-4), (measured, period)
