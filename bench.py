@@ -37,6 +37,126 @@ def algorithmic_bytes_per_env_step(m):
     return 8 * 2 * (nq + 2 * nv) + 4 * nu + 4 * obs + 8 * 16 + 2 + 8 + 2 * 8 + 4
 
 
+F64_VALU_PEAK_TF = 78.6   # MI355X vector f64 peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz), MI355X_MICROARCH.md
+F32_MFMA_PEAK_TF = 157.3  # dense f32 matrix-core peak (v_mfma_f32_*_f32), same guide
+
+
+def mfma_probe(torch, dev, learner, opponent, env, obs_b, ret_b, act_b, val_b, nlp_b, nmb_rows, reps=20):
+    """MFMA side of the roofline, measured live with HIP events on the launching stream: `reps` back-to-back calls of ppo_grad on one
+    PPO2 minibatch (forward + backward + weight-gradient MFMAs of both nets; the call also runs the two slab-reduction kernels,
+    which are counted in the time but not in the flops) and of ppo_selfplay_forward on one env group (the 5 evaluations of a
+    rollout step)."""
+    import ctypes as C
+    from robosumo_selfplay_amd import ppo_capi
+    L = ppo_capi.lib()
+    D, A = learner.spec.ob_dim, learner.spec.ac_dim
+    S = {"st": torch.cuda.current_stream(dev).cuda_stream}
+    n = int(nmb_rows)
+    idx = torch.randperm(obs_b.shape[0], device=dev)[:n].to(torch.int32)
+    adv = torch.randn(n, device=dev)
+    w = torch.ones(obs_b.shape[0], device=dev)
+    lr = torch.empty(n, device=dev)
+    stats = torch.zeros(ppo_capi.NSTATS, dtype=torch.float64, device=dev)
+    grads = torch.zeros_like(learner.grads)
+    call_g = lambda: ppo_capi.chk(L.ppo_grad(learner.params.data_ptr(), obs_b.data_ptr(), obs_b.stride(0), D, A, act_b.data_ptr(), adv.data_ptr(),
+                                             ret_b.data_ptr(), nlp_b.data_ptr(), w.data_ptr(), idx.data_ptr(), n, 1.0 / n, 0.2, 0.0, 0.5,
+                                             grads.data_ptr(), stats.data_ptr(), lr.data_ptr(), learner.workspace.data_ptr(), S["st"]))
+    ng = env.group_size
+    f32 = torch.float32
+    outs = [torch.empty((ng, D), dtype=f32, device=dev), torch.empty((ng, D), dtype=f32, device=dev)] + \
+           [torch.empty((ng, A), dtype=f32, device=dev) for _ in range(2)] + [torch.empty(ng, dtype=f32, device=dev) for _ in range(6)]
+    fp = (C.c_void_p * 10)(*[x.data_ptr() for x in outs])
+    dn = [torch.empty(ng, dtype=torch.uint8, device=dev) for _ in range(2)]
+    dp = (C.c_void_p * 2)(dn[0].data_ptr(), dn[1].data_ptr())
+    noise = [torch.randn((ng, A), device=dev) for _ in range(2)]
+    act_env = torch.empty((ng, 2, A), dtype=f32, device=dev)
+    ob = env.obs_dev[:ng]
+    call_s = lambda: ppo_capi.chk(L.ppo_selfplay_forward(learner.params.data_ptr(), opponent.params.data_ptr(), ob.data_ptr(), ng, ob.stride(0),
+                                                         ob.stride(1), D, A, noise[0].data_ptr(), noise[1].data_ptr(), env.done_dev[:ng].data_ptr(),
+                                                         act_env.data_ptr(), fp, dp, S["st"]))
+    res = {}
+    pi = D * 64 + 64 * 64 + 64 * A
+    vf = D * 64 + 64 * 64 + 64
+    for name, call, flops in (("ppo_grad_kernel", call_g, 3.0 * 2.0 * (pi + vf) * n),                    # fwd + dX + dW, SURVEY.md 8(d)
+                              ("ppo_selfplay_kernel", call_s, 2.0 * (2 * (2 * pi + vf)) * ng)):         # both sides: 2 policy trunks + value
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize(dev)
+        # the calls are replayed from a HIP graph so that the GPU, not the Python enqueue loop, sets the pace
+        eager = S["st"]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            S["st"] = torch.cuda.current_stream(dev).cuda_stream
+            for _ in range(reps):
+                call()
+        S["st"] = eager
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        tf = flops / (us * 1e-6) / 1e12
+        res[name] = {"achieved": tf, "frac": tf / F32_MFMA_PEAK_TF, "us_per_call": us, "flops_per_call": flops,
+                     "rows_per_call": n if name == "ppo_grad_kernel" else ng}
+    res["ppo_grad_kernel"]["note"] = "time of the whole ppo_grad call (gradient kernel + two slab-reduction launches); flops of the gradient kernel"
+    return res
+
+
+def spider_segment(torch, dev, local_rank, args, hp):
+    """Secondary driver-timed line (BASELINE config 4): RoboSumo-Spider-vs-Spider-v0, same number of envs, same rollout step."""
+    from robosumo_selfplay_amd import mjcf
+    from robosumo_selfplay_amd.model import PPOModel
+    from robosumo_selfplay_amd.policies import build_policy
+    from robosumo_selfplay_amd.runner import Runner
+    from robosumo_selfplay_amd.vec_env import SumoVecEnv
+    env_id = "RoboSumo-Spider-vs-Spider-v0"
+    N = args.envs
+    env = SumoVecEnv(env_id, num_envs=N, seed=77, device=local_rank, model=mjcf.load_model(env_id), groups=args.groups)
+    spec = build_policy(env, "mlp", value_network=hp["value_network"], num_hidden=hp["num_hidden"], activation=hp["activation"])
+    ms = [PPOModel(policy=spec, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, trainable=False, model_scope="model_%d" % i, device=local_rank)
+          for i in range(2)]
+    ms[1].set_param_list(ms[0].get_param_list())
+    r = Runner(env=env, models=ms, nsteps=8, nagent=2, gamma=hp["gamma"], lam=hp["lam"], rho_bar=hp["rho_bar"], c_bar=hp["c_bar"])
+    r.fused_rollout = not args.stepwise
+    fused = r.fused_ok()
+    K = args.spider_steps
+    B = r._alloc_device(max(K, 8) if fused else 8)
+    T = B["T"]
+
+    def advance(n):
+        if fused:
+            for s0 in range(0, n, T):
+                r._steps_fused(B, 0, min(T, n - s0), 1.0)
+        else:
+            for k in range(n):
+                r._step_device(B, k % 8, 1.0)
+    advance(args.state_warmup + 5)
+    r.join_groups()
+    torch.cuda.synchronize(dev)
+    st0 = env.stats()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    advance(K)
+    r.join_groups()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    st1 = env.stats()
+    nf = max(1.0, st1["forward"] - st0["forward"])
+    out = {"env_id": env_id, "envs": N, "steps": args.spider_steps, "env_steps_per_s": N * args.spider_steps / dt,
+           "ms_per_step": dt / args.spider_steps * 1e3, "gpu_ms": e0.elapsed_time(e1), "rollout_path": "fused" if fused else "stepwise",
+           "envs_per_launch": env.group_size, "lds_bytes_per_env": env.engine.lds_bytes,
+           "waves_per_cu": int(160 * 1024 // env.engine.lds_bytes), "mean_contacts_per_forward": (st1["contacts"] - st0["contacts"]) / nf,
+           "mean_newton_iters_per_forward": (st1["newton"] - st0["newton"]) / nf,
+           "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env.model)}
+    env.close()
+    return out
+
+
 def cpu_baseline(model, states, actions, steps, threads):
     """Times the CPU oracle (the float64 restatement; the reference's MuJoCo path cannot run here) on a bounded
     sample of the same workload: the first len(states[0]) envs of the GPU batch, same states, same action law."""
@@ -61,12 +181,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--env-id", default="RoboSumo-Ant-vs-Ant-v0")
-    ap.add_argument("--groups", type=int, default=2, help="env groups per GPU, each stepped on its own stream (1 = one launch for all envs)")
+    ap.add_argument("--groups", type=int, default=0, help="env groups per GPU (0 = 1 with the fused rollout launch, 2 with the step-by-step launches: "
+                    "each group is stepped on its own stream there)")
+    ap.add_argument("--stepwise", action="store_true", help="time the step-by-step launches (ppo_selfplay_forward + sumo_step + ppo_post_step per "
+                    "rollout step) instead of the fused rollout launch (sumo_rollout_steps: all timed steps in one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-envs", type=int, default=512)
-    ap.add_argument("--cpu-sample-steps", type=int, default=60)
+    ap.add_argument("--cpu-sample-envs", type=int, default=1024)
+    ap.add_argument("--cpu-sample-steps", type=int, default=300)
     ap.add_argument("--ppo-nsteps", type=int, default=128, help="rollout length of the PPO2 update timed after the main region (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the cgroup CPU quota of this job (hostcfg.cpu_quota)")
+    ap.add_argument("--no-mfma-probe", action="store_true")
+    ap.add_argument("--spider-steps", type=int, default=30, help="timed rollout steps of the secondary Spider-vs-Spider 4096-env line (0 = skip)")
     ap.add_argument("--state-warmup", type=int, default=100,
                     help="untimed rollout steps that bring the env states from the reset law to the steady workload (SURVEY.md 8(d): >= 100)")
     args = ap.parse_args()
@@ -107,6 +232,8 @@ def main():
 
     model = mjcf.load_model(args.env_id)
     N = args.envs
+    if args.groups <= 0:
+        args.groups = 2 if args.stepwise else 1
     env = SumoVecEnv(args.env_id, num_envs=N, seed=1000 + rank * N, device=local_rank, model=model, groups=args.groups)
     from robosumo_selfplay_amd import defaults
     from robosumo_selfplay_amd.model import PPOModel
@@ -133,15 +260,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    ring = 8
+    runner.fused_rollout = not args.stepwise
+    fused = runner.fused_ok()
+    ring = max(8, args.steps, args.warmup) if fused else 8
     B = runner._alloc_device(ring)
+
+    def advance(k0, n, events=None):
+        """n rollout steps starting at running step index k0: fused = one launch per pass over the ring (the timed region of K steps
+        is ONE launch), else one launch chain per step."""
+        if fused:
+            done = 0
+            while done < n:
+                s0 = (k0 + done) % ring
+                c = min(n - done, ring - s0)
+                if events is not None:
+                    events[0].record()
+                runner._steps_fused(B, s0, c, alpha)
+                if events is not None:
+                    events[1].record()
+                done += c
+        else:
+            for k in range(n):
+                runner._step_device(B, (k0 + k) % ring, alpha, env_events=(ev0[k], ev1[k]) if events is not None and ev_every and k % ev_every == 0 else None)
     # workload priming (not a timing knob): the reset law drops every agent from z = 1.25 at the same instant; >= 100 rollout
     # steps under the initial policy's N(0,1)-scale actions spread the episodes out and make contacts active (SURVEY.md 8(d))
-    for k in range(args.state_warmup):
-        runner._step_device(B, k % ring, alpha)
+    advance(0, args.state_warmup)
+    runner.join_groups()
     torch.cuda.synchronize(dev)
-    for k in range(args.warmup):                                   # timing warm-up
-        runner._step_device(B, (args.state_warmup + k) % ring, alpha)
+    k0 = ((args.state_warmup + ring - 1) // ring) * ring       # fused: warm-up and the timed region each start a pass over the ring
+    advance(k0, args.warmup)                                   # timing warm-up
+    runner.join_groups()
     torch.cuda.synchronize(dev)
     st0 = env.stats()
     states = None
@@ -152,20 +300,22 @@ def main():
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_every = int(os.environ.get("BENCH_EVENT_EVERY", "1"))       # HIP events around the env launch of every n-th step (0 = none)
+    timed = [k for k in range(args.steps) if ev_every and k % ev_every == 0]
+    k0 += ((args.warmup + ring - 1) // ring) * ring
     barrier()
     thr0 = hostcfg.throttle_stats()
     t0 = time.perf_counter()
-    ev_every = int(os.environ.get("BENCH_EVENT_EVERY", "1"))       # HIP events around the env launch of every n-th step (0 = none)
-    timed = [k for k in range(args.steps) if ev_every and k % ev_every == 0]
-    k0 = args.state_warmup + args.warmup
-    for k in range(args.steps):
-        runner._step_device(B, (k0 + k) % ring, alpha, env_events=(ev0[k], ev1[k]) if ev_every and k % ev_every == 0 else None)
+    advance(k0, args.steps, events=(ev0[0], ev1[0]))
+    runner.join_groups()
     barrier()
     dt = time.perf_counter() - t0
     thr1 = hostcfg.throttle_stats()
-    kern_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in timed])) if timed else float("nan")
+    if fused:
+        timed = [0]
+    kern_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in timed])) if timed else float("nan")   # fused: the K-step launch
     st1 = env.stats()
-    sample_acts = [B["act"][:, k].permute(1, 0, 2).contiguous() for k in range(ring)]   # [N, 2, A] per step
+    sample_acts = [B["act"][:, k].permute(1, 0, 2).contiguous() for k in range(8)]   # [N, 2, A] per step
 
     # ---- "+ PPO2 iters/sec": one full update, outside the timed region above
     ppo = None
@@ -196,6 +346,12 @@ def main():
                    "rollout_s": float(tt[1].item()), "sgd_s": float(tt[0].item() - tt[1].item()),
                    "samples_per_iter": nb * world}
 
+    mfma = None
+    if args.ppo_nsteps > 0 and rank == 0 and not args.no_mfma_probe:
+        mfma = mfma_probe(torch, dev, learner, opponent, env, obs_b, ret_b, act_b, val_b, nlp_b, nb // nmb)
+    spider = None
+    if args.spider_steps > 0 and rank == 0 and "Ant-vs-Ant" in args.env_id:
+        spider = spider_segment(torch, dev, local_rank, args, hp)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -205,14 +361,31 @@ def main():
         total_steps = N * world * args.steps
         value = total_steps / dt_max
         B = algorithmic_bytes_per_env_step(model)
-        traffic = None
-        try:   # PMC traffic is collected offline with rocprofv3 (profiles/README.md); reported only for the profiled config
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")))   # newest collection
-            if ("<%d>" % model.nv) in pj["kernel"] and pj["envs"] == env.group_size:
-                traffic = pj["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        achieved = B * env.group_size / (kern_ms * 1e-3) / 1e9      # per launch: one env group (HIP events on its stream)
+        # PMC figures are collected offline with rocprofv3 (profiles/README.md; separate --pmc passes as MI355X_MICROARCH.md
+        # prescribes) and are only quoted for the configuration they were profiled on; every one names its file
+        kernel_name = "sumo_rollout_kernel" if fused else "sumo_step_kernel"
+        steps_per_launch = env.group_size * (args.steps if fused else 1)          # env steps one launch advances
+
+        def profile_json(name):
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                ok = ("<%d>" % model.nv) in pj["kernel"] and kernel_name in pj["kernel"] and pj["envs"] == env.group_size
+                return pj if ok else None
+            except Exception:
+                return None
+        traffic, traffic_src = None, None
+        for cand in ("r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01f_pmc_traffic.json"):
+            pj = profile_json(cand)
+            if pj is not None:          # per env step in the profile, scaled to this launch's env steps
+                traffic, traffic_src = pj["traffic_bytes_per_env_step"] * steps_per_launch, "profiles/" + cand
+                break
+        sq, sq_src = None, None
+        for cand in ("r02b_pmc_sq.json", "r02_pmc_sq.json"):
+            sq = profile_json(cand)
+            if sq is not None:
+                sq_src = "profiles/" + cand
+                break
+        achieved = B * steps_per_launch / (kern_ms * 1e-3) / 1e9      # per launch (HIP events on its stream)
         nfwd = max(1.0, st1["forward"] - st0["forward"])
         out = {
             "metric": "env-steps/sec (whole node), RoboSumoAnts-v0 4096 envs, + PPO2 iters/sec",
@@ -222,6 +395,8 @@ def main():
             "config": {"workload": "%s, %d envs per GPU, MLP(64,64) policy+value: one self-play rollout step per bench step "
                                    "(5 policy/value evaluations + env step of frame_skip 5 x RK4 + reward mix), random-init "
                                    "networks, auto-reset on" % (args.env_id, N),
+                       "rollout_path": "fused: the timed steps are one sumo_rollout_steps launch per env group" if fused else
+                                       "stepwise: ppo_selfplay_forward + sumo_step + ppo_post_step launches per step",
                        "ppo2": ppo,
                        "state_warmup_steps": args.state_warmup,
                        "envs_per_gpu": N, "env_groups_per_gpu": env.groups, "total_envs": N * world, "parallelism": "env-shard x%d" % world,
@@ -229,22 +404,53 @@ def main():
                        "mean_newton_iters_per_forward": (st1["newton"] - st0["newton"]) / nfwd,
                        "lds_bytes_per_env": env.engine.lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sumo_step_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": B,
-                         "envs_per_launch": env.group_size, "concurrent_launches": env.groups,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": B,
+                         "envs_per_launch": env.group_size, "env_steps_per_launch": steps_per_launch, "concurrent_launches": env.groups,
                          "aggregate_achieved": B * value / max(1, world) / 1e9,
                          "note": "latency/ALU-bound physics: ~20 forward-dynamics solves per 2.4 KB of state traffic"},
         }
+        if sq is not None:
+            # ALU side of the physics kernel: the f64 instruction mix counted by the SQ (flops as ISSUED over 64 lanes; the
+            # kernel keeps 28-44 of them busy) scaled by the live env-step rate, and the share of SIMD issue time the VALU holds
+            d = sq["derived"]
+            fl = d["f64_flops_issued_per_env_step"]
+            tf = fl * value / max(1, world) / 1e12
+            out["roofline_alu"] = {"bound": "valu_f64", "kernel": kernel_name, "achieved": tf, "peak": F64_VALU_PEAK_TF,
+                                   "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TF, "f64_flops_issued_per_env_step": fl,
+                                   "valu_issue_frac": d["valu_issue_frac"], "valu_active_frac_of_wave_cycles": d.get("active_valu_frac"),
+                                   "waiting_frac_of_wave_cycles": d.get("wait_any_frac"), "mean_active_lanes": d.get("mean_active_lanes"),
+                                   "source": sq_src,
+                                   "note": "flops = (ADD+MUL+TRANS + 2 FMA) f64 wave-instructions x 64 lanes per env step from the profile, times the live rate"}
+        if mfma is not None:
+            out["roofline_mfma"] = dict(mfma, bound="mfma", peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", dtype="f32 (v_mfma_f32_16x16x4_f32)")
+        if spider is not None:
+            out["config"]["spider"] = spider
         out["host"] = {"cpu_model": hostcfg.cpu_model(), "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": hostcfg.cpu_quota(),
                        "pool_threads": hostcfg.apply(),
                        "throttled_periods_in_timed_region": None if thr0 is None or thr1 is None else thr1[0] - thr0[0]}
         if states is not None:
+            # the reference's CPU path (mujoco-py + SubprocVecEnv) cannot run offline; the C restatement is timed in the three shapes
+            # BASELINE.md 3 lists: B2 OpenMP over envs on every core of this job's quota (the headline figure), B1 one thread,
+            # B3 eight single-env worker processes behind pipes like subproc_vec_env.py:6-32,65-76 (config 1's shape)
             threads = args.cpu_threads or hostcfg.cpu_quota()
             cpu_acts = [a[:states[0].shape[0]].cpu().numpy() for a in sample_acts]
             v = cpu_baseline(model, states, cpu_acts, args.cpu_sample_steps, threads)
             out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",
                                    "sample": "%d envs x %d steps of the same warmed-up workload, OpenMP over envs"
                                              % (states[0].shape[0], args.cpu_sample_steps)}
+            n1 = min(128, states[0].shape[0])
+            s1 = tuple(x[:n1] for x in states)
+            v1 = cpu_baseline(model, s1, [a[:n1] for a in cpu_acts], max(10, args.cpu_sample_steps // 3), 1)
+            out["cpu_baseline"]["single_thread"] = {"value": v1, "cores": 1, "sample": "%d envs x %d steps, one thread"
+                                                    % (n1, max(10, args.cpu_sample_steps // 3))}
+            try:
+                from oracle import subproc_baseline
+                v3 = subproc_baseline.run(args.env_id, 8, 1500, model.act_dims[0])
+                out["cpu_baseline"]["subproc8"] = {"value": v3, "cores": 8, "sample": "8 single-env worker processes x 1500 lock-step steps over pipes "
+                                                   "(from the reset law, N(0,1) actions)"}
+            except Exception as e:                                    # the harness is a report, never a reason to lose the bench line
+                out["cpu_baseline"]["subproc8"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:

@@ -50,6 +50,38 @@ int sumo_reset(sumo_handle_t h, const uint64_t* seeds_host /* [E] or NULL */, co
                float* obs_dev, void* stream);
 int sumo_step(sumo_handle_t h, const float* actions_dev, float* obs_dev, double* info_dev, uint8_t* done_dev,
               double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream);
+/* K consecutive self-play rollout steps of every env of the engine in ONE launch: replaces the body of Runner.run's step loop
+ * (runner.py:62-151: the five policy / value evaluations, env.step, the reward curriculum, the buffer appends) together with
+ * the SubprocVecEnv round trip (subproc_vec_env.py:65-76) for MLP(64,64) policies (policies.py:14-128, baselines models.py:74-103,
+ * distributions.py:227-251).  The wavefront that owns an env evaluates the learner's policy and value nets and the opponent's
+ * policy net on the env's two observations on the matrix cores, samples both actions (action = mean + exp(logstd) * noise),
+ * scores each with the other net, steps the env and appends to the rollout buffers; nothing is launched and no env waits for
+ * another between two steps.  Results equal sumo_step + ppo_selfplay_forward + ppo_post_step called step by step, bit for bit.
+ *   parameters: flat float32 vectors in the sumo_ppo.h layout; opponent_params holds npool frozen snapshots [npool][P] and
+ *     opponent_index[e] (NULL = all 0) selects the snapshot env e plays against (the reference loads ONE snapshot for all envs
+ *     per update, alg_ppo.py:213-214: npool = 1)
+ *   noise0 / noise1 float32 [T][E][ac_dim]: standard-normal draws for the learner's (agent 0) / the opponent's (agent 1) actions
+ *   rollout buffers, agent-major like Runner's mb_* lists: obs [2][T][Ntot][ob_dim], act [2][T][Ntot][ac_dim], rew / val / nlp
+ *     (learner's neglogp) / onlp (opponent's neglogp) float32 [2][T][Ntot], done uint8 [2][T][Ntot] (flags BEFORE each step),
+ *     ep_done uint8 / ep_r float64 / ep_l int32 [T][Ntot] (agent 0's episode records, monitor.py:63-78); this engine's envs are
+ *     columns env_offset .. env_offset + E - 1; steps s0 .. s0 + K - 1 are written
+ *   alpha: weight of the shaping reward (runner.py:130-134)
+ * The env-side buffers are those of sumo_step (actions is written: it receives the sampled actions). */
+typedef struct sumo_rollout {
+  const float* learner_params;
+  const float* opponent_params;
+  const int32_t* opponent_index;
+  int npool, ob_dim, ac_dim;
+  int T, Ntot, env_offset, s0, K;
+  double alpha;
+  const float *noise0, *noise1;
+  float *obs, *act, *rew, *val, *nlp, *onlp;
+  uint8_t *done, *ep_done;
+  double* ep_r;
+  int32_t* ep_l;
+} sumo_rollout;
+int sumo_rollout_steps(sumo_handle_t h, const sumo_rollout* r, float* actions_dev, float* obs_dev, double* info_dev, uint8_t* done_dev,
+                       double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream);
 int sumo_get_state(sumo_handle_t h, double* qpos, double* qvel, double* warm, int32_t* counters /* [E][2] */);
 int sumo_set_state(sumo_handle_t h, const double* qpos, const double* qvel, const double* warm,
                    const int32_t* counters);
@@ -57,8 +89,9 @@ int sumo_set_state(sumo_handle_t h, const double* qpos, const double* qvel, cons
  * qacc (HOST float64 [E][nv]) plus per-env {ncon, nefc, newton iterations, dropped contacts} (HOST int32 [E][4]). */
 int sumo_debug_forward(sumo_handle_t h, const double* ctrl, double* qacc, int32_t* counts);
 /* device-side statistics accumulated since creation: forward calls, newton iterations, contacts, efc rows,
- * max ncon, max nefc, max newton iterations, dropped contacts, diverged env steps (HOST float64 [SUMO_NSTATS]). */
-#define SUMO_NSTATS 9
+ * max ncon, max nefc, max newton iterations, dropped contacts, diverged env steps, aborted waits of the fused rollout's step
+ * hand-over (always 0 unless a launch was cut short) (HOST float64 [SUMO_NSTATS]). */
+#define SUMO_NSTATS 10
 int sumo_stats(sumo_handle_t h, double* out);
 /* per-phase shader-cycle totals (20 phases + 4 ad-hoc probe slots); all zero unless the library was built with
  * -DSUMO_PROFILE (HOST float64 [24]). */

@@ -38,7 +38,7 @@ def build_all(force=False, verbose=False):
         if not all(os.path.exists(s) for s in srcs):
             continue
         tpath = os.path.join(_CSRC, target)
-        deps = srcs + [os.path.join(inc, h) for h in os.listdir(inc)]
+        deps = srcs + [os.path.join(inc, h) for h in os.listdir(inc)] + [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")]
         if force or _stale(tpath, deps):
             cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-shared", "-I", inc, "-o", tpath] + srcs
             if verbose:

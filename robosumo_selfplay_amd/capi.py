@@ -12,12 +12,22 @@ from . import build as _build
 
 INFO_STRIDE = 8
 NDIMS = 16
-NSTATS = 9
+NSTATS = 10
 _LIB = None
 
 
 class SumoHipError(RuntimeError):
     pass
+
+
+class Rollout(C.Structure):
+    """``sumo_rollout`` of include/sumo_hip.h (device pointers as integers)."""
+    _fields_ = [("learner_params", C.c_void_p), ("opponent_params", C.c_void_p), ("opponent_index", C.c_void_p),
+                ("npool", C.c_int), ("ob_dim", C.c_int), ("ac_dim", C.c_int),
+                ("T", C.c_int), ("Ntot", C.c_int), ("env_offset", C.c_int), ("s0", C.c_int), ("K", C.c_int),
+                ("alpha", C.c_double), ("noise0", C.c_void_p), ("noise1", C.c_void_p),
+                ("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("val", C.c_void_p), ("nlp", C.c_void_p), ("onlp", C.c_void_p),
+                ("done", C.c_void_p), ("ep_done", C.c_void_p), ("ep_r", C.c_void_p), ("ep_l", C.c_void_p)]
 
 
 def lib():
@@ -35,6 +45,7 @@ def lib():
         L.sumo_dims.argtypes = [vp, vp]
         L.sumo_reset.argtypes = [vp, vp, vp, vp, vp]
         L.sumo_step.argtypes = [vp] * 9
+        L.sumo_rollout_steps.argtypes = [vp, C.POINTER(Rollout)] + [vp] * 8
         L.sumo_get_state.argtypes = [vp] * 5
         L.sumo_set_state.argtypes = [vp] * 5
         L.sumo_debug_forward.argtypes = [vp] * 4
@@ -43,14 +54,14 @@ def lib():
         L.sumo_debug_trace.argtypes = [vp, vp]
         L.sumo_debug_trace.restype = i32
         L.sumo_profile.restype = i32
-        for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_get_state",
+        for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps", "sumo_get_state",
                   "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
             getattr(L, n).restype = i32
         _LIB = L
     return _LIB
 
 
-EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step",
+EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps",
            "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace")
 
 
@@ -99,6 +110,10 @@ class Engine:
     def step(self, actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream=None):
         _chk(lib().sumo_step(self.h, actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream))
 
+    def rollout_steps(self, ro, actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream=None):
+        """K fused self-play rollout steps (``sumo_rollout_steps``); ``ro`` is a filled :class:`Rollout`."""
+        _chk(lib().sumo_rollout_steps(self.h, C.byref(ro), actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream))
+
     def get_state(self):
         qpos = np.zeros((self.N, self.nq))
         qvel = np.zeros((self.N, self.nv))
@@ -143,4 +158,4 @@ class Engine:
         o = np.zeros(NSTATS)
         _chk(lib().sumo_stats(self.h, _np(o)))
         return dict(forward=o[0], newton=o[1], contacts=o[2], efc=o[3], max_ncon=o[4], max_nefc=o[5],
-                    max_newton=o[6], dropped=o[7], diverged=o[8])
+                    max_newton=o[6], dropped=o[7], diverged=o[8], rollout_aborts=o[9])

@@ -19,48 +19,17 @@
 #include "../../include/sumo_ppo.h"
 
 #define WAVE 64
-#define H PPO_HIDDEN
-#define HS 66         /* LDS row stride of a 16 x 64 activation tile (== 2 mod 32) */
-#define MAXA 16       /* action dims are padded to one 16-column MFMA tile */
-#define LOG2PI_F 1.8378770664093453f
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#include "ppo_tile.h"   /* parameter layout + the one-wave / one-tile trunk and Gaussian-head device functions (shared with sumo_engine.hip) */
+#define H PT_H
+#define HS PT_HS
+#define MAXA PT_MAXA
+#define LOG2PI_F PT_LOG2PI_F
+#define MFMA PT_MFMA
 
 static thread_local char g_err[256];
 extern "C" const char* ppo_last_error(void) { return g_err; }
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return code; } while (0)
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) FAIL(-100, "%s failed: %s", #expr, hipGetErrorString(_e)); } while (0)
-
-struct ParamLayout {  // offsets into the flat parameter vector (checkpoint order)
-  int D, A, P;
-  int pi_w0, pi_b0, pi_w1, pi_b1, vf_w0, vf_b0, vf_w1, vf_b1, pi_w, pi_b, logstd, vf_w, vf_b;
-};
-static ParamLayout make_layout(int D, int A) {
-  ParamLayout L;
-  L.D = D; L.A = A;
-  int o = 0;
-  L.pi_w0 = o; o += D * H; L.pi_b0 = o; o += H; L.pi_w1 = o; o += H * H; L.pi_b1 = o; o += H;
-  L.vf_w0 = o; o += D * H; L.vf_b0 = o; o += H; L.vf_w1 = o; o += H * H; L.vf_b1 = o; o += H;
-  L.pi_w = o; o += H * A; L.pi_b = o; o += A; L.logstd = o; o += A; L.vf_w = o; o += H; L.vf_b = o; o += 1;
-  L.P = o;
-  return L;
-}
-extern "C" int ppo_param_count(int ob_dim, int ac_dim) { return make_layout(ob_dim, ac_dim).P; }
-
-static int x_stride(int D) {  // LDS row stride of the staged observation tile: >= 16*ceil(D/16), == 2 mod 32
-  int cols = ((D + 15) / 16) * 16;
-  int s = cols;
-  while (s % 32 != 2) s++;
-  return s;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// shared device pieces: one wave, one 16-row tile, one trunk
-// ---------------------------------------------------------------------------------------------------------
-struct Net { const float *w0, *b0, *w1, *b1, *w2, *b2; int nout; };
-
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
 // stage 16 rows of obs (row ids from idx, or consecutive) into xbuf[16][XS], zero padded
 // (optional observation filter of the policy-zoo nets: clip((x - mean) * invstd, -clip, clip))
@@ -93,95 +62,6 @@ __device__ __forceinline__ void stage_x(float* xbuf, int XS, const float* obs, i
       for (int r = 0; r < 16; r++) xbuf[r * XS + c] = v[r];
     }
   }
-}
-
-// forward of one trunk on the staged tile.  h1buf/h2buf [16][HS] receive the relu activations; returns the head tile
-// (D layout: lane (i = lane&15, kq = lane>>4) holds rows 4kq+r, column i; columns >= nout are zero + garbage-free).
-template <bool TANH = false>
-__device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf, int XS, int D, float* h1buf, float* h2buf, int lane) {
-  const int i = lane & 15, kq = lane >> 4;
-  const int Dp = (D + 3) & ~3;
-  f32x4 acc[4];
-#pragma unroll
-  for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
-  // k-steps are issued eight at a time with all of their operand loads in flight first (32 weight loads per batch): the
-  // accumulation order is unchanged, but one memory round trip is exposed per batch instead of one per k-step
-  for (int k0 = 0; k0 < Dp; k0 += 32) {
-    float a[8], b[8][4];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int k = k0 + 4 * u + kq;
-      const bool ok = k < D;
-      a[u] = ok ? xbuf[i * XS + k] : 0.0f;
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) b[u][ct] = ok ? net.w0[k * H + ct * 16 + i] : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (k0 + 4 * u < Dp) {
-#pragma unroll
-        for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a[u], b[u][ct], acc[ct]);
-      }
-  }
-#pragma unroll
-  for (int ct = 0; ct < 4; ct++) {
-    float bias = net.b0[ct * 16 + i];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { float z = acc[ct][r] + bias; h1buf[(4 * kq + r) * HS + ct * 16 + i] = TANH ? tanhf(z) : fmaxf(z, 0.0f); }
-    acc[ct] = (f32x4){0, 0, 0, 0};
-  }
-  wave_sync();
-  {
-    float b[H / 4][4];
-#pragma unroll
-    for (int u = 0; u < H / 4; u++)
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) b[u][ct] = net.w1[(4 * u + kq) * H + ct * 16 + i];
-#pragma unroll
-    for (int u = 0; u < H / 4; u++) {
-      const float a = h1buf[i * HS + 4 * u + kq];
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a, b[u][ct], acc[ct]);
-    }
-  }
-#pragma unroll
-  for (int ct = 0; ct < 4; ct++) {
-    float bias = net.b1[ct * 16 + i];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { float z = acc[ct][r] + bias; h2buf[(4 * kq + r) * HS + ct * 16 + i] = TANH ? tanhf(z) : fmaxf(z, 0.0f); }
-  }
-  wave_sync();
-  f32x4 out = (f32x4){0, 0, 0, 0};
-  const bool col_ok = i < net.nout;
-  {
-    float b[H / 4];
-#pragma unroll
-    for (int u = 0; u < H / 4; u++) b[u] = col_ok ? net.w2[(4 * u + kq) * net.nout + i] : 0.0f;
-#pragma unroll
-    for (int u = 0; u < H / 4; u++) out = MFMA(h2buf[i * HS + 4 * u + kq], b[u], out);
-  }
-  float bias = col_ok ? net.b2[i] : 0.0f;
-#pragma unroll
-  for (int r = 0; r < 4; r++) out[r] += bias;
-  return out;
-}
-
-__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes that share lane>>4
-  v += __shfl_xor(v, 1, WAVE); v += __shfl_xor(v, 2, WAVE); v += __shfl_xor(v, 4, WAVE); v += __shfl_xor(v, 8, WAVE);
-  return v;
-}
-__device__ __forceinline__ float kq_sum(float v) {  // sum over the 4 lanes that share lane&15
-  v += __shfl_xor(v, 16, WAVE); v += __shfl_xor(v, 32, WAVE);
-  return v;
-}
-
-__device__ __forceinline__ Net pi_net(const float* p, const ParamLayout& L) {
-  Net n = {p + L.pi_w0, p + L.pi_b0, p + L.pi_w1, p + L.pi_b1, p + L.pi_w, p + L.pi_b, L.A};
-  return n;
-}
-__device__ __forceinline__ Net vf_net(const float* p, const ParamLayout& L) {
-  Net n = {p + L.vf_w0, p + L.vf_b0, p + L.vf_w1, p + L.vf_b1, p + L.vf_w, p + L.vf_b, 1};
-  return n;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -295,27 +175,6 @@ struct SelfplayArgs {
   int n, env_stride, agent_stride, XS;
   ParamLayout L;
 };
-
-// Gaussian head on a policy tile (D layout): samples (noise != nullptr) or scores `act`; returns the row's neglogp in
-// the lanes with i == 0 via nlp[r]
-__device__ __forceinline__ void gauss_head(const float* params, const ParamLayout& L, const f32x4& mean, const float* noise, int r0, int n,
-                                           int lane, float (&act)[4], float (&nlp)[4]) {
-  const int i = lane & 15, kq = lane >> 4, A = L.A;
-  const bool col = i < A;
-  const float logstd = col ? params[L.logstd + i] : 0.0f;
-  const float std = expf(logstd);
-  const float sum_logstd = row16_sum(logstd);
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = r0 + 4 * kq + r;
-    const bool ok = col && row < n;
-    const float m = mean[r];
-    if (noise) act[r] = ok ? m + std * noise[(size_t)row * A + i] : m;
-    const float z = ok ? (act[r] - m) / std : 0.0f;
-    const float ss = row16_sum(z * z);
-    nlp[r] = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
-  }
-}
 
 __global__ void __launch_bounds__(192) ppo_selfplay_kernel(SelfplayArgs a) {
   // three waves per (tile, side): wave 0 the acting net's policy trunk (samples), wave 1 the scoring net's policy trunk,
@@ -832,7 +691,7 @@ __global__ void ppo_reward_mix_kernel(const double* info, int n, double alpha, f
   if (t >= 2 * n) return;
   int e = t >> 1, g = t & 1;
   const double* I = info + (size_t)(2 * e + g) * 8;
-  out[(size_t)g * agent_stride + e] = (float)(alpha * I[6] + (1 - alpha) * I[3]);  // runner.py:134
+  out[(size_t)g * agent_stride + e] = reward_mix(alpha, I[6], I[3]);
 }
 // reward mix plus the episode records of the step (monitor.py:63-78 harvest): one launch instead of four
 __global__ void ppo_post_step_kernel(const double* info, int n, double alpha, float* out, int agent_stride, const uint8_t* done,
@@ -841,7 +700,7 @@ __global__ void ppo_post_step_kernel(const double* info, int n, double alpha, fl
   if (t >= 2 * n) return;
   int e = t >> 1, g = t & 1;
   const double* I = info + (size_t)(2 * e + g) * 8;
-  out[(size_t)g * agent_stride + e] = (float)(alpha * I[6] + (1 - alpha) * I[3]);  // runner.py:134
+  out[(size_t)g * agent_stride + e] = reward_mix(alpha, I[6], I[3]);
   if (g == 0) { ep_done_out[e] = done[2 * e]; ep_r_out[e] = ep_r[e]; ep_l_out[e] = ep_l[e]; }
 }
 extern "C" int ppo_post_step(const double* info, int n, double alpha, float* reward_out, int agent_stride, const uint8_t* done,

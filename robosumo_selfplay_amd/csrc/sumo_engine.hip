@@ -26,6 +26,7 @@
 
 #include "../../include/sumo_hip.h"
 #include "../../include/sumo_model.h"
+#include "ppo_tile.h"   /* MLP(64,64) trunk / Gaussian head on one MFMA tile: the policy phase of the fused rollout kernel */
 
 #define WAVE 64
 #ifndef SUMO_WPE
@@ -74,7 +75,7 @@ struct Layout {  // LDS offsets in doubles unless noted
   int xpos, xquat, xipos, gaxis, xanchor, xaxis, com, cinert, cdof, abuf, cfrc;  // "kin scratch"
   int H;                                                                           // aliases kin scratch
   int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim;
-  int stash;     // 4 doubles parked across the step loop
+  int stash;     // 4 doubles parked across the step loop (+ 2 for the fused rollout's ticket)
   int cmask;     // per dof: 64-bit mask of the contacts whose Jacobian touches the dof
   int cond, Jb, cpar, cW, cp, jar, D, aref;
   int limD, limA;  // joint-limit slots, hinge-indexed: [nhinge] lower side | [nhinge] upper side (D = 0: side not active)
@@ -417,7 +418,7 @@ struct Ctx {
 #endif
   // statistics accumulated over the launch
   int st_forward, st_newton, st_ncon, st_nefc, st_maxcon, st_maxefc, st_maxnewton, st_dropped, st_dense, st_cross;
-  int diverged;   // wave-uniform: the state failed MuJoCo's bad-value test (state_is_bad) during this env step
+  int st_diverged;   // env steps of this launch whose state failed MuJoCo's bad-value test (state_is_bad)
   int hcross;
 };
 
@@ -427,6 +428,8 @@ struct Ctx {
 // within 256 registers, i.e. two waves per SIMD.
 template <class T>
 __device__ __forceinline__ const T* launder_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; }
+template <class T>
+__device__ __forceinline__ const T* launder_sptr(const T* p) { asm volatile("" : "+s"(p)); return p; }   // wave-uniform pointer (SGPR pair)
 #define KCONSTS() const LaneRec K = *launder_ptr(c.kp)
 // mass matrix element (i, j) of the block-diagonal storage; valid when i and j belong to the same agent tree
 #define MIDX(i, j) ((i) * c.L.mld + ((j) >= c.L.d1 ? (j) - c.L.d1 : (j)))
@@ -1966,7 +1969,7 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   __syncthreads();
   c.ncon = c.nlim = c.nefc = c.ndropped = c.use_prev = 0;
   c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = c.st_dense = c.st_cross = 0;
-  c.diverged = 0;
+  c.st_diverged = 0;
 #ifdef SUMO_PROFILE
   for (int k = 0; k < 24; k++) c.prof[k] = 0;
   c.tprev = clock64();
@@ -1999,7 +2002,7 @@ __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
     atomicMax(stats + 5, (unsigned long long)c.st_maxefc);
     atomicMax(stats + 6, (unsigned long long)c.st_maxnewton);
     atomicAdd(stats + 7, (unsigned long long)c.st_dropped);
-    if (c.diverged) atomicAdd(stats + 8, 1ull);
+    if (c.st_diverged) atomicAdd(stats + 8, (unsigned long long)c.st_diverged);
 #ifdef SUMO_PROFILE
     for (int k = 0; k < 24; k++) atomicAdd(stats + 16 + k, c.prof[k]);
 #endif
@@ -2036,17 +2039,14 @@ __device__ __forceinline__ void sched_rank(const int* __restrict__ cost, int n, 
 
 extern __shared__ double smem_dyn[];
 
-template <int NV>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE, SUMO_WPE))) sumo_step_kernel(const Params* P, StepArgs a) {
-  Ctx<NV> c;
-  ctx_init(c, P, smem_dyn);
-  const sumo_model_t& mdl = P->mdl;
+// One env step of env `e` by this wave: state record -> LDS, frame_skip x RK4 mj_step, game rules, rewards, done, auto-reset,
+// observation write, state record back (the whole of SumoEnv._step + the wrappers + the worker's auto-reset:
+// sumo.py:120-202, sumo_env.py:40-72, monitor.py:51-78, subproc_vec_env.py:10-19).  Shared by the per-step launch
+// (sumo_step_kernel) and the fused multi-step rollout launch (sumo_rollout_kernel).
+template <class C>
+__device__ __forceinline__ void env_step_body(C& c, const StepArgs& a, int e) {
+  const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane;
-  if ((int)blockIdx.x < a.rank_blocks) { sched_rank(a.rank_cost, a.N, a.rank_perm, blockIdx.x, lane); return; }
-  const int bid = (int)blockIdx.x - a.rank_blocks;
-  if (bid >= a.N) return;
-  const int e = a.perm ? a.perm[bid] : bid;
-  if (a.perm && bid < (a.N >> 3)) __builtin_amdgcn_s_setprio(1);   // predicted-longest eighth of the launch: issue ahead of the SIMD mate
   if (a.trace && lane == 0) a.trace[4 * e] = wall_clock64();
   load_state(c, a, e);
   if (lane < mdl.nu) {
@@ -2112,7 +2112,7 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   // per-env divergence guard: a state that failed the bad-value test (during the stepping or after its last mj_step) ends the
   // episode with zero rewards and info flag 4; the auto-reset below replaces it, the engine counts it (sumo_stats[8])
   const int diverged = state_is_bad(c);
-  c.diverged = diverged;
+  c.st_diverged += diverged;
   if (diverged) {
 #pragma unroll
     for (int g = 0; g < 2; g++) {
@@ -2147,12 +2147,185 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   // (a contention-independent proxy; sorting by the measured cycle count of the previous step schedules no better)
   // (least-squares fit of measured wave times, tools/slot_trace.py: Newton iterations, contacts, dense-path forwards)
   if (lane == 0 && a.cost) { const int w = 1000 + 12 * c.st_newton + 10 * c.st_ncon + 60 * c.st_dense; a.cost[e] = w < 65535 ? w : 65535; }
-  flush_stats(c, a.stats);
   if (a.trace && lane == 0) {
     a.trace[4 * e + 1] = wall_clock64();
     a.trace[4 * e + 2] = (unsigned long long)c.st_newton | ((unsigned long long)c.st_ncon << 32);
     a.trace[4 * e + 3] = (unsigned long long)c.st_dense | ((unsigned long long)c.st_cross << 16) | ((unsigned long long)c.st_nefc << 32);
   }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE, SUMO_WPE))) sumo_step_kernel(const Params* P, StepArgs a) {
+  Ctx<NV> c;
+  ctx_init(c, P, smem_dyn);
+  const int lane = c.lane;
+  if ((int)blockIdx.x < a.rank_blocks) { sched_rank(a.rank_cost, a.N, a.rank_perm, blockIdx.x, lane); return; }
+  const int bid = (int)blockIdx.x - a.rank_blocks;
+  if (bid >= a.N) return;
+  const int e = a.perm ? a.perm[bid] : bid;
+  if (a.perm && bid < (a.N >> 3)) __builtin_amdgcn_s_setprio(1);   // predicted-longest eighth of the launch: issue ahead of the SIMD mate
+  env_step_body(c, a, e);
+  flush_stats(c, a.stats);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused rollout: K consecutive self-play rollout steps of an env in ONE launch (reference runner.py:62-151 for MLP(64,64)
+// policies).  The wave that owns env e evaluates the five policy / value passes of a step itself -- the env's two
+// observations are rows 0 and 1 of an MFMA tile, the three trunks (learner policy, opponent policy, learner value) run through
+// the same device functions as the batched PPO kernels, so every number equals the stepwise path bit for bit -- records
+// obs / actions / values / neglogps / done flags straight into the [agent][time][env] rollout buffers, steps its env and
+// records the mixed reward and the episode statistics.  No launch boundary, no policy launch and no per-step barrier over
+// the envs remain between two env steps; each env may face its own frozen opponent snapshot (opp_idx).
+// ---------------------------------------------------------------------------------------------------------
+struct RolloutArgs {
+  const float *learner, *opponent;   // flat parameter vectors; opponent: [npool][P]
+  const int32_t* opp_idx;            // [N] snapshot per env or NULL
+  const float *noise0, *noise1;      // [T][N][A]
+  float *obs, *act, *rew, *val, *nlp, *onlp;   // [2][T][Ntot][...]
+  uint8_t *done, *ep_done;           // [2][T][Ntot], [T][Ntot]
+  double* ep_r;                      // [T][Ntot]
+  int32_t* ep_l;                     // [T][Ntot]
+  double alpha;
+  int T, Ntot, env_offset, s0, K, XS, lds_off;   // lds_off: LDS offset (doubles) of the policy scratch (the mass-matrix region)
+  int* sched;                        // ticket counter | abort flag | finished steps per env [N] (zeroed by the host per launch)
+  unsigned long long* prof;          // development (sumo_debug_trace): [N][4] wave start, end, ticks in the policy phases, ticks in the env steps (100 MHz)
+  ParamLayout L;
+};
+
+template <class C>
+__device__ __forceinline__ void rollout_policy_phase(C& c, const StepArgs& a, const RolloutArgs& r, int e, int s) {
+  const int lane = c.lane, i = lane & 15, kq = lane >> 4;
+  const int D = r.L.D, A = r.L.A, XS = r.XS;
+  float* xbuf = (float*)(c.sm + r.lds_off);        // [2][XS] | h1 [2][PT_HS] | h2 [2][PT_HS]
+  float* h1 = xbuf + 2 * XS;
+  float* h2 = h1 + 2 * PT_HS;
+  const size_t col = (size_t)r.env_offset + e;
+  const size_t slot0 = ((size_t)0 * r.T + s) * r.Ntot + col, slot1 = ((size_t)1 * r.T + s) * r.Ntot + col;
+  // the env's two observations: into the tile and into the rollout record (runner.py:98-101)
+  const float* ob = a.obs + (size_t)e * 2 * a.obs_stride;
+  for (int k = lane; k < D; k += WAVE) {
+    const float o0 = ob[k], o1 = ob[a.obs_stride + k];
+    xbuf[k] = o0; xbuf[XS + k] = o1;
+    r.obs[slot0 * D + k] = o0; r.obs[slot1 * D + k] = o1;
+  }
+  if (lane < 2) r.done[lane == 0 ? slot0 : slot1] = a.done[2 * e + lane];
+  wave_sync();
+  const float* lp = r.learner;
+  const float* op = r.opponent + (size_t)(r.opp_idx ? r.opp_idx[e] : 0) * r.L.P;
+  const f32x4 mL = trunk_forward<false, 2>(pi_net(lp, r.L), xbuf, XS, D, h1, h2, lane);
+  wave_sync();
+  const f32x4 mO = trunk_forward<false, 2>(pi_net(op, r.L), xbuf, XS, D, h1, h2, lane);
+  wave_sync();
+  const f32x4 vL = trunk_forward<false, 2>(vf_net(lp, r.L), xbuf, XS, D, h1, h2, lane);
+  // heads: row 0 = agent 0 (learner acts, opponent scores), row 1 = agent 1 (opponent acts, learner scores and values)
+  const bool colk = i < A;
+  const float lsL = colk ? lp[r.L.logstd + i] : 0.0f, lsO = colk ? op[r.L.logstd + i] : 0.0f;
+  const float stdL = expf(lsL), stdO = expf(lsO);
+  const float sumL = row16_sum(lsL), sumO = row16_sum(lsO);
+  const bool ok = colk && kq == 0;                  // rows 0 and 1 live in the first 16 lanes (D layout: rows 4 kq + r)
+  const size_t nz = ((size_t)s * a.N + e) * A + i;
+  const float n0 = ok ? r.noise0[nz] : 0.0f, n1 = ok ? r.noise1[nz] : 0.0f;
+  float act0 = 0.0f, act1 = 0.0f;
+  const float nlp0 = gauss_row(mL[0], stdL, sumL, ok, true, n0, act0, A);      // learner samples for agent 0 ...
+  const float onlp0 = gauss_row(mO[0], stdO, sumO, ok, false, 0.0f, act0, A);  // ... the opponent net scores that action
+  const float onlp1 = gauss_row(mO[1], stdO, sumO, ok, true, n1, act1, A);     // opponent samples for agent 1 ...
+  const float nlp1 = gauss_row(mL[1], stdL, sumL, ok, false, 0.0f, act1, A);   // ... the learner scores it
+  if (ok) {
+    r.act[slot0 * A + i] = act0; r.act[slot1 * A + i] = act1;
+    float* ae = const_cast<float*>(a.actions) + (size_t)e * 2 * a.act_stride;
+    ae[i] = act0; ae[a.act_stride + i] = act1;
+  }
+  if (lane == 0) {
+    r.nlp[slot0] = nlp0; r.nlp[slot1] = nlp1; r.onlp[slot0] = onlp0; r.onlp[slot1] = onlp1;
+    r.val[slot0] = vL[0]; r.val[slot1] = vL[1];
+  }
+  wave_sync();   // the action buffer is read back by the env step (other lanes), the scratch region becomes the mass matrix again
+}
+
+template <class C>
+__device__ __forceinline__ void rollout_post_phase(C& c, const StepArgs& a, const RolloutArgs& r, int e, int s) {
+  wave_sync();   // info / done / episode records of the step were written by other lanes
+  const int lane = c.lane;
+  const size_t col = (size_t)r.env_offset + e;
+  if (lane < 2) {   // runner.py:134 + monitor.py:63-78 harvest, as ppo_post_step_kernel
+    const double* I = a.info + (size_t)(2 * e + lane) * SUMO_INFO_STRIDE;
+    r.rew[((size_t)lane * r.T + s) * r.Ntot + col] = reward_mix(r.alpha, I[6], I[3]);
+    if (lane == 0) {
+      const size_t t = (size_t)s * r.Ntot + col;
+      r.ep_done[t] = a.done[2 * e]; r.ep_r[t] = a.ep_r[e]; r.ep_l[t] = a.ep_l[e];
+    }
+  }
+}
+
+// The launch arguments live in device memory and are re-read through a laundered pointer in every iteration: as by-value
+// kernel arguments their loads are loop-invariant, get hoisted out of the step loop and stay live across the twenty
+// forward-dynamics evaluations of every step (the kernel sits exactly at its 256-register budget).
+struct RolloutLaunch { StepArgs a; RolloutArgs r; };
+
+// Scheduling: the launch is a set of persistent waves (one per wave slot of the chip) that draw TICKETS from a global counter;
+// ticket t is step t / N of env t % N.  Env steps differ in cost by 3x (contacts, Newton iterations, agents wrestling), so
+// binding a wave to one env for the whole launch leaves a fifth of the slots idle behind the slowest envs (measured: 40-step
+// wave lifetimes of 34 ms mean, 50 ms max); with tickets a wave that drew a long step simply draws fewer of them.  A step needs
+// its env's previous step: prog[e] counts the finished steps of env e, the wave that draws (e, k) waits for prog[e] == k
+// (rarely: that ticket was handed out N tickets earlier).  Dependencies only point to earlier tickets, which are held by waves
+// that are already running, so the scheme cannot deadlock whatever the number of resident waves; every wave leaves when the
+// tickets run out.  Hand-over of an env between waves goes through HBM: agent-scope release after the step's stores, relaxed
+// store of prog[e]; the next wave polls prog[e] with one lane and acquires at agent scope before its plain loads
+// (MI355X_MICROARCH.md, inter-workgroup visibility).  The wait is bounded: a wave that saw no progress for ~2 s raises the
+// launch's abort flag (counted in sumo_stats[9]) and every wave drains.
+#define ROLLOUT_SPIN_LIMIT (1u << 22)   /* polls of ~0.5 us each */
+
+template <int NV>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE, SUMO_WPE)))
+sumo_rollout_kernel(const Params* P, const RolloutLaunch* LP) {
+  Ctx<NV> c;
+  ctx_init(c, P, smem_dyn);
+  for (;;) {
+    const RolloutLaunch* lp = launder_sptr(LP);
+    int* sched = lp->r.sched;                      // [0] ticket counter, [1] abort flag, [2 + e] finished steps of env e
+    const int N = lp->a.N;
+    int t = 0;
+    if (c.lane == 0) t = __hip_atomic_fetch_add(sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= N * lp->r.K) break;
+    int e = t % N, k = t / N;
+    if (k > 0) {
+      int ok = 1;
+      if (c.lane == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(sched + 2 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > ROLLOUT_SPIN_LIMIT || __hip_atomic_load(sched + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+        }
+        if (!ok) __hip_atomic_store(sched + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      ok = __builtin_amdgcn_readfirstlane(ok);
+      if (!ok) { if (c.lane == 0 && lp->a.stats) atomicAdd(lp->a.stats + 9, 1ull); break; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    // (e, k) wait in LDS during the phases (nothing but the context stays live across the forward-dynamics evaluations)
+    if (c.lane == 0) { int* tk = (int*)(S(stash) + 4); tk[0] = e; tk[1] = k; }
+    lp = launder_sptr(LP);
+    int s = lp->r.s0 + k;
+    unsigned long long* prof = lp->r.prof;
+    if (prof && c.lane == 0) { const unsigned long long tk = wall_clock64(); if (k == 0) { prof[4 * e] = tk; prof[4 * e + 2] = 0; prof[4 * e + 3] = 0; } prof[4 * e + 2] -= tk; }
+    rollout_policy_phase(c, lp->a, lp->r, e, s);
+    prof = launder_sptr(LP)->r.prof;
+    if (prof && c.lane == 0) { const unsigned long long tk = wall_clock64(); prof[4 * e + 2] += tk; prof[4 * e + 3] -= tk; }
+    env_step_body(c, launder_sptr(LP)->a, e);
+    SYNC();
+    { const int* tk = (const int*)(S(stash) + 4); e = __builtin_amdgcn_readfirstlane(tk[0]); k = __builtin_amdgcn_readfirstlane(tk[1]); }
+    asm volatile("" : "+s"(e), "+s"(k));
+    lp = launder_sptr(LP);
+    s = lp->r.s0 + k;
+    rollout_post_phase(c, lp->a, lp->r, e, s);
+    prof = lp->r.prof;
+    if (prof && c.lane == 0) { const unsigned long long tk = wall_clock64(); prof[4 * e + 3] += tk; prof[4 * e + 1] = tk; }
+    // hand the env over: all of this wave's stores of the step, then the progress counter
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (c.lane == 0) __hip_atomic_store(launder_sptr(LP)->r.sched + 2 + e, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  flush_stats(c, launder_sptr(LP)->a.stats);
 }
 
 template <int NV>
@@ -2231,6 +2404,8 @@ struct sumo_engine {
   // longest-first scheduling of the env steps (see sumo_step)
   int *d_cost = nullptr, *d_cost_sorted = nullptr, *d_iota = nullptr, *d_perm = nullptr;   // d_cost / d_perm: two buffers of N each
   unsigned long long* d_trace = nullptr;   // sumo_debug_trace
+  void* d_launch = nullptr;                // sumo_rollout_steps: the launch's argument block (RolloutLaunch)
+  int* d_rsched = nullptr;                 // sumo_rollout_steps: ticket counter, abort flag, per-env progress [2 + N]
   long long sched_t = 0;                                                                     // step launches so far (in-kernel ranking)
   void* d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
@@ -2614,7 +2789,7 @@ static void build_layout(sumo_engine* E) {
   }
   L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = 0;
   L.search = take(nv); L.bias = L.search;   // the bias force is consumed (into qsm) before the solver writes its search direction
-  L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv); L.stash = take(4);
+  L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv); L.stash = take(6);   // + the fused rollout's (env, step) of the ticket in flight
   // contact records live from the narrow phase to the Jacobian build only: they borrow the mass matrix's storage
   if (L.msize < 14 * L.maxcon) L.msize = 14 * L.maxcon;
   if (L.msize < 12 * nb) L.msize = 12 * nb;      // ... and so do the velocity-pass temporaries (abuf, cfrc), see below
@@ -2755,7 +2930,7 @@ extern "C" int sumo_destroy(sumo_handle_t E) {
   if (!E) return 0;
   (void)hipSetDevice(E->device);
   (void)hipFree(E->d_params); (void)hipFree(E->d_lanes); (void)hipFree(E->d_pair_rec); (void)hipFree(E->d_pair_bound); (void)hipFree(E->d_blob); (void)hipFree(E->d_ai); (void)hipFree(E->d_af); (void)hipFree(E->d_pic); (void)hipFree(E->d_state);
-  (void)hipFree(E->d_counters); (void)hipFree(E->d_seeds); (void)hipFree(E->d_stats);
+  (void)hipFree(E->d_counters); (void)hipFree(E->d_seeds); (void)hipFree(E->d_stats); (void)hipFree(E->d_launch); (void)hipFree(E->d_rsched);
   (void)hipFree(E->d_cost); (void)hipFree(E->d_cost_sorted); (void)hipFree(E->d_iota); (void)hipFree(E->d_perm); (void)hipFree(E->d_sort_tmp);
   delete E;
   return 0;
@@ -2848,6 +3023,65 @@ extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_d
                                           (size_t)E->N, 0, 16, (hipStream_t)stream));
     E->perm_valid = true;
   }
+  return 0;
+}
+
+extern "C" int sumo_rollout_steps(sumo_handle_t E, const sumo_rollout* ro, float* actions_dev, float* obs_dev, double* info_dev,
+                                  uint8_t* done_dev, double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream) {
+  if (!E || !ro || !actions_dev || !obs_dev || !info_dev || !done_dev || !ep_r_dev || !ep_dr_dev || !ep_l_dev) FAIL(-1, "bad arguments");
+  if (!ro->learner_params || !ro->opponent_params || !ro->noise0 || !ro->noise1 || !ro->obs || !ro->act || !ro->rew || !ro->val ||
+      !ro->nlp || !ro->onlp || !ro->done || !ro->ep_done || !ro->ep_r || !ro->ep_l)
+    FAIL(-2, "sumo_rollout: missing buffer");
+  const sumo_model_t* m = &E->hm;
+  const int* anq = SUMO_I(m, agent_nq); const int* anv = SUMO_I(m, agent_nv); const int* anb = SUMO_I(m, agent_nbody);
+  const int* anu = SUMO_I(m, agent_nu);
+  const int od0 = anq[0] + anv[0] + 6 * anb[0] + 14, od1 = anq[1] + anv[1] + 6 * anb[1] + 14;
+  if (od0 != od1 || anu[0] != anu[1]) FAIL(-3, "fused rollout needs a homogeneous match-up (one observation / action space for both sides, runner.py:14-16)");
+  if (ro->ob_dim != od0 || ro->ac_dim != anu[0] || ro->ac_dim > PT_MAXA) FAIL(-4, "ob_dim %d / ac_dim %d do not match the scene (%d / %d)", ro->ob_dim, ro->ac_dim, od0, anu[0]);
+  if (ro->T < 1 || ro->K < 1 || ro->s0 < 0 || ro->s0 + ro->K > ro->T) FAIL(-5, "steps [%d, %d) outside the rollout buffers (T = %d)", ro->s0, ro->s0 + ro->K, ro->T);
+  if (ro->env_offset < 0 || ro->env_offset + E->N > ro->Ntot) FAIL(-6, "envs [%d, %d) outside the rollout buffers (N = %d)", ro->env_offset, ro->env_offset + E->N, ro->Ntot);
+  if (ro->npool < 1) FAIL(-7, "npool %d", ro->npool);
+  HIPCHK(hipSetDevice(E->device));
+  RolloutArgs r;
+  memset(&r, 0, sizeof r);
+  r.learner = ro->learner_params; r.opponent = ro->opponent_params; r.opp_idx = ro->opponent_index; r.noise0 = ro->noise0; r.noise1 = ro->noise1;
+  r.obs = ro->obs; r.act = ro->act; r.rew = ro->rew; r.val = ro->val; r.nlp = ro->nlp; r.onlp = ro->onlp; r.done = ro->done;
+  r.ep_done = ro->ep_done; r.ep_r = ro->ep_r; r.ep_l = ro->ep_l; r.alpha = ro->alpha;
+  r.T = ro->T; r.Ntot = ro->Ntot; r.env_offset = ro->env_offset; r.s0 = ro->s0; r.K = ro->K;
+  r.XS = x_stride(ro->ob_dim); r.L = make_layout(ro->ob_dim, ro->ac_dim); r.lds_off = E->L.M;
+  r.prof = E->d_trace;   // development: sumo_debug_trace(stamps) switches the per-wave phase clock on
+  if ((size_t)(2 * r.XS + 4 * PT_HS) * sizeof(float) > (size_t)E->L.msize * sizeof(double))
+    FAIL(-8, "policy scratch (%zu B) does not fit the mass-matrix region (%zu B)", (size_t)(2 * r.XS + 4 * PT_HS) * sizeof(float), (size_t)E->L.msize * sizeof(double));
+  RolloutLaunch rl;
+  rl.a = base_args(E);
+  StepArgs& a = rl.a;
+  a.actions = actions_dev; a.obs = obs_dev; a.info = info_dev; a.done = done_dev; a.ep_r = ep_r_dev; a.ep_dr = ep_dr_dev; a.ep_l = ep_l_dev;
+  rl.r = r;
+  hipStream_t st_ = (hipStream_t)stream;
+  if (!E->d_launch) HIPCHK(hipMalloc(&E->d_launch, sizeof(RolloutLaunch)));
+  if (!E->d_rsched) HIPCHK(hipMalloc((void**)&E->d_rsched, (size_t)(2 + E->N) * sizeof(int)));
+  HIPCHK(hipMemsetAsync(E->d_rsched, 0, (size_t)(2 + E->N) * sizeof(int), st_));
+  rl.r.sched = E->d_rsched;
+  // stream-ordered: the previous launch of this engine (same stream) has finished reading the block before it is overwritten
+  HIPCHK(hipMemcpyAsync(E->d_launch, &rl, sizeof rl, hipMemcpyHostToDevice, st_));
+  {
+    // persistent waves: as many as the chip holds at this kernel's LDS footprint (8 per CU at most: two per SIMD)
+    int slots = (int)((size_t)160 * 1024 / (size_t)E->L.total_bytes);
+    if (slots > 4 * SUMO_WPE) slots = 4 * SUMO_WPE;
+    if (slots < 1) slots = 1;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, E->device));
+    long long nw = (long long)slots * prop.multiProcessorCount;
+    if (nw > (long long)E->N) nw = E->N;   // more waves than envs would only wait on each other's steps
+    dim3 g_((unsigned)nw), b_(WAVE);
+    size_t lds_ = (size_t)E->L.total_bytes;
+    const RolloutLaunch* lp_ = (const RolloutLaunch*)E->d_launch;
+    if (!for_kernel_variant(E->hm.nv, [&](auto nvc_) {
+          hipLaunchKernelGGL(sumo_rollout_kernel<decltype(nvc_)::value>, g_, b_, lds_, st_, E->d_params, lp_);
+        }))
+      FAIL(-19, "no kernel variant for nv=%d", E->hm.nv);
+  }
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

@@ -6,6 +6,8 @@ Two modes, same arithmetic (csrc/ppo_kernels.hip: reward curriculum, IS ratios, 
   * host mode    -- any duck-typed VecEnv / models like the reference's: numpy per step (their API), then the collected
     buffers go through the same kernels; ``run`` returns numpy arrays (this is what the golden-vector tests drive).
 """
+import os
+
 import numpy as np
 
 from . import ppo_capi
@@ -27,6 +29,14 @@ def anneal_alpha(update, anneal_bound):
     if update <= anneal_bound:
         return float(np.linspace(1, 0, anneal_bound)[update - 1])
     return 0.0
+
+
+class _nullctx(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 class AbstractEnvRunner(object):
@@ -53,6 +63,11 @@ class Runner(AbstractEnvRunner):
         self._side = None
         self._gstreams = None
         self._gsides = None
+        # device mode, MLP policies: the whole step loop of a rollout runs inside the env engine's fused rollout launch
+        # (sumo_rollout_steps); SUMO_FUSED_ROLLOUT=0 keeps the step-by-step launches (same numbers, bit for bit)
+        self.fused_rollout = os.environ.get("SUMO_FUSED_ROLLOUT", "1") != "0"
+        self.rollout_chunk = int(os.environ.get("SUMO_ROLLOUT_CHUNK", "0"))   # steps per launch (0 = the whole rollout)
+        self.opponent_pool = None     # opponent_pool.OpponentPool: frozen snapshots + per-env snapshot index (fused path)
         self.recurrent = all(getattr(m, "recurrent", False) for m in models)
         self.device_mode = hasattr(env, "step_device") and (self.recurrent or all(
             hasattr(m, "act_model") and hasattr(m.act_model, "evaluate") for m in models))
@@ -132,6 +147,61 @@ class Runner(AbstractEnvRunner):
         for g in range(G):
             with t.cuda.stream(self._gstreams[g]):
                 self._step_group(B, s, alpha, g, self.env._gs(g), env_events if g == 0 else None)
+
+    def _group_streams(self):
+        t = self._t
+        G = getattr(self.env, "groups", 1)
+        if G > 1 and self._gstreams is None:
+            cur = t.cuda.current_stream(self.device)
+            self._gstreams = [t.cuda.Stream(device=self.device) for _ in range(G)]
+            self._gsides = [None] * G
+            for st in self._gstreams:
+                st.wait_stream(cur)
+        return self._gstreams
+
+    def fused_ok(self):
+        """The fused rollout launch applies to device mode with two plain MLP policies of the env's own observation / action shape."""
+        if not (self.device_mode and self.fused_rollout and not self.recurrent and hasattr(self.env, "rollout_steps_group")):
+            return False
+        m0, m1 = self.models[0], self.models[1]
+        if not (hasattr(m0, "act_model") and hasattr(m1, "act_model")):
+            return False
+        return self._fused_ok(m0.act_model, m1.act_model)
+
+    def _steps_fused(self, B, s0, K, alpha):
+        """Rollout steps s0 .. s0+K-1 of every env group, one launch per group (``sumo_rollout_steps``): the five evaluations of
+        runner.py:62-96, env.step, the reward curriculum and the appends to ``B`` all happen inside the env engine.  Noise comes
+        from each acting model's own generator, drawn per group for the whole buffer when its first step is written -- the same
+        draws as the step-by-step path, hence the same rollout bit for bit."""
+        from . import capi
+        t = self._t
+        env = self.env
+        learner, opp = self.models[0].act_model, self.models[1].act_model
+        G = getattr(env, "groups", 1)
+        streams = self._group_streams() if G > 1 else [None]
+        pool = self.opponent_pool
+        D, A, T, N = learner.spec.ob_dim, learner.spec.ac_dim, B["T"], self.nenv
+        for g in range(G):
+            sl = env._gs(g)
+            n = sl.stop - sl.start
+            ctx = t.cuda.stream(streams[g]) if streams[g] is not None else _nullctx()
+            with ctx:
+                key = ("noise", sl.start)
+                if s0 == 0 or key not in B:
+                    B[key] = (t.randn((T, n, A), generator=learner.gen, device=self.device, dtype=t.float32),
+                              t.randn((T, n, A), generator=opp.gen, device=self.device, dtype=t.float32))
+                ro = capi.Rollout()
+                ro.learner_params = learner.params.data_ptr()
+                if pool is None:
+                    ro.opponent_params, ro.opponent_index, ro.npool = opp.params.data_ptr(), None, 1
+                else:
+                    ro.opponent_params, ro.opponent_index, ro.npool = pool.params.data_ptr(), pool.index[sl].data_ptr(), pool.capacity
+                ro.ob_dim, ro.ac_dim, ro.T, ro.Ntot, ro.env_offset, ro.s0, ro.K, ro.alpha = D, A, T, N, sl.start, int(s0), int(K), float(alpha)
+                ro.noise0, ro.noise1 = B[key][0].data_ptr(), B[key][1].data_ptr()
+                for f in ("obs", "act", "rew", "val", "nlp", "onlp", "done", "ep_done", "ep_r", "ep_l"):
+                    setattr(ro, f, B[f].data_ptr())
+                env.rollout_steps_group(g, ro)
+        self.obs, self.dones = env.obs_dev, env.done_dev
 
     def join_groups(self):
         """Make the current stream wait for every env group's stream (no-op without groups)."""
@@ -261,8 +331,15 @@ class Runner(AbstractEnvRunner):
             cur = t.cuda.current_stream(self.device)
             for st in self._gstreams:
                 st.wait_stream(cur)
-        for s in range(T):
-            self._step_device(B, s, alpha)
+        if self.fused_ok():
+            chunk = self.rollout_chunk if self.rollout_chunk > 0 else T
+            for s0 in range(0, T, chunk):
+                self._steps_fused(B, s0, min(chunk, T - s0), alpha)
+        else:
+            if self.opponent_pool is not None:
+                raise NotImplementedError("a per-env opponent pool needs the fused rollout path (MLP policies, SUMO_FUSED_ROLLOUT != 0)")
+            for s in range(T):
+                self._step_device(B, s, alpha)
         self.join_groups()
         learner = self.models[0].act_model
         last_values = t.empty((2, N), dtype=t.float32, device=self.device)

@@ -130,6 +130,15 @@ class SumoVecEnv(VecEnv):
                              self.done_dev[sl].data_ptr(), self.ep_r_dev[sl].data_ptr(), self.ep_dr_dev[sl].data_ptr(),
                              self.ep_l_dev[sl].data_ptr(), stream=self._stream())
 
+    def rollout_steps_group(self, g, ro):
+        """K fused self-play rollout steps of group ``g`` on the current stream (``capi.Engine.rollout_steps``): policies, env
+        steps and the appends to the rollout buffers in one launch.  ``ro`` is a ``capi.Rollout`` whose ``env_offset`` is the
+        group's first env."""
+        sl = self._gs(g)
+        self.engines[g].rollout_steps(ro, self.act_dev[sl].data_ptr(), self.obs_dev[sl].data_ptr(), self.info_dev[sl].data_ptr(),
+                                      self.done_dev[sl].data_ptr(), self.ep_r_dev[sl].data_ptr(), self.ep_dr_dev[sl].data_ptr(),
+                                      self.ep_l_dev[sl].data_ptr(), stream=self._stream())
+
     def step_device(self, actions):
         """actions: float32 CUDA tensor [N, 2, act_stride]. Returns (obs, info, done, ep_r, ep_dr, ep_l) tensors that
         are overwritten by the next call."""

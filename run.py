@@ -37,7 +37,8 @@ def main(argv):
     ap.add_argument("--algo", default="ppo")
     ap.add_argument("--log_path", default="results")
     ap.add_argument("--suffix", default="0")
-    ap.add_argument("--env_groups", type=int, default=2, help="env groups per GPU, stepped on separate streams (vec_env.SumoVecEnv)")
+    ap.add_argument("--env_groups", type=int, default=0, help="env groups per GPU (vec_env.SumoVecEnv): 0 = 1 for MLP policies (their whole "
+                    "rollout is one fused launch that balances the envs itself), 2 for recurrent policies (step-by-step launches on two streams)")
     args, unknown = ap.parse_known_args(argv)
     extra = parse_unknown(unknown)
     from robosumo_selfplay_amd import alg_ppo, defaults, dist as sdist
@@ -49,6 +50,8 @@ def main(argv):
         shutil.rmtree(log_path, ignore_errors=True)                        # run.py:233-234
         os.makedirs(log_path, exist_ok=True)
     start, per = sdist.shard_envs(args.num_env, rank, world)
+    if args.env_groups <= 0:
+        args.env_groups = 2 if (args.network == "lstm" or os.environ.get("SUMO_FUSED_ROLLOUT", "1") == "0") else 1
     groups = args.env_groups if per % max(1, args.env_groups) == 0 else 1
     env = make_vec_env(args.env, per, args.seed + start, device=local_rank, groups=groups)  # run.py:144: env i gets seed + i
     kw = defaults.get_default_params(args.env, args.algo)

@@ -430,3 +430,80 @@ def test_grouped_rollout_and_update():
         st = learner.train_indexed(1e-3, 0.2, obs[0].contiguous(), returns[0], actions[0], values[0], nlp[0], w, None, 64 * 24)
         assert np.isfinite(st[:5]).all()
     env.close()
+
+
+def _rollout_pair(env_id, N, T, groups, fused, seed=3, pool=None, opp_params=None):
+    env = SumoVecEnv(env_id, num_envs=N, seed=11, groups=groups)
+    D, A = env.observation_space[0].shape[0], env.action_space[0].shape[0]
+    learner, opp = _model(D, A, seed=seed, trainable=False), _model(D, A, seed=seed + 1, trainable=False)
+    _perturb(learner, np.random.RandomState(seed)); _perturb(opp, np.random.RandomState(seed + 1))
+    if opp_params is not None:
+        opp.params.copy_(opp_params)
+    learner.act_model.seed(101); opp.act_model.seed(202)
+    r = Runner(env=env, models=[learner, opp], nsteps=T, nagent=2, gamma=0.995, lam=0.95, rho_bar=1.0, c_bar=1.0, anneal_bound=500)
+    r.fused_rollout = fused
+    if pool is not None:
+        r.opponent_pool = pool(learner.spec, N, env.device)
+    outs = [r.run(250), r.run(251)]                     # two consecutive rollouts: episode state carries over
+    torch.cuda.synchronize()
+    st = [E.get_state() for E in env.engines]
+    stats = env.stats()
+    env.close()
+    return outs, st, stats
+
+
+@pytest.mark.parametrize("env_id,N,T,groups", [("RoboSumo-Ant-vs-Ant-v0", 96, 24, 1), ("RoboSumo-Ant-vs-Ant-v0", 64, 12, 2),
+                                               ("RoboSumo-Spider-vs-Spider-v0", 32, 8, 1)])
+def test_rollout_kernel_matches_stepwise_path(env_id, N, T, groups):
+    """sumo_rollout_steps (policies + env steps + buffer appends of a whole rollout in ONE launch) against the step-by-step
+    launches it replaces (ppo_selfplay_forward, sumo_step, ppo_post_step per step): every returned array of Runner.run, the
+    episode records and the env states are bit-identical."""
+    fo, fs, fstat = _rollout_pair(env_id, N, T, groups, True)
+    so, ss, sstat = _rollout_pair(env_id, N, T, groups, False)
+    names = ["obs", "returns", "masks", "actions", "values", "neglogpacs", "rewards", "opp_neglogpacs", "opp_obs", "opp_actions", "states",
+             "epinfos", "off_policy_ratio", "off_env_ratio", "total_ratio"]
+    for f, s_ in zip(fo, so):
+        for k, (x, y) in enumerate(zip(f, s_)):
+            if torch.is_tensor(x):
+                assert torch.equal(x, y), names[k]
+            else:
+                assert x == y, names[k]
+    for (a, b) in zip(fs, ss):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    for k in ("forward", "newton", "contacts", "efc", "dropped", "diverged"):
+        assert fstat[k] == sstat[k], k
+    assert len(fo[1][11]) > 0 or T * N < 500            # episodes did end inside the fused launches (auto-reset path covered)
+
+
+def test_rollout_kernel_opponent_pool_per_env():
+    """Per-env opponent snapshots (BASELINE config 5's pool on one shard): a fused rollout against a pool of three snapshots
+    equals, env by env, the step-by-step rollout against that env's snapshot alone."""
+    from robosumo_selfplay_amd.opponent_pool import OpponentPool
+    env_id, N, T = "RoboSumo-Ant-vs-Ant-v0", 48, 10
+    rng = np.random.RandomState(9)
+    snaps = []
+    for k in range(3):
+        m = _model(121, 8, seed=40 + k, trainable=False)
+        _perturb(m, rng, 0.2)
+        snaps.append(m.params.clone())
+    idx = rng.randint(0, 3, N)
+
+    def pool(spec, n, dev):
+        p = OpponentPool(spec, 4, n, dev)
+        for k, v in enumerate(snaps):
+            p.set_snapshot(k, v, label="snap%d" % k)
+        p.assign(idx)
+        return p
+    fo, _, _ = _rollout_pair(env_id, N, T, 1, True, pool=pool)
+    assert (np.bincount(idx, minlength=3) > 0).all()
+    for k in range(3):
+        so, _, _ = _rollout_pair(env_id, N, T, 1, False, opp_params=snaps[k])
+        cols = np.nonzero(idx == k)[0]
+        rows = torch.from_numpy((cols[:, None] * T + np.arange(T)[None, :]).ravel()).to(DEV)     # env-major flattening (sf01)
+        for j in (0, 1, 3, 4, 5, 6, 7):
+            assert torch.equal(fo[0][j][:, rows], so[0][j][:, rows]), (k, j)
+    with pytest.raises(ValueError):
+        p = OpponentPool(policies.PolicySpec(121, 8, value_network="copy", activation="relu"), 4, N, DEV)
+        p.set_snapshot(0, snaps[0])
+        p.assign(np.full(N, 2))                           # empty slot

@@ -1,13 +1,30 @@
 """Dev tool: turn `rocprofv3 --pmc ... --output-format csv` counter dumps into the JSON summaries kept under profiles/.
 
 usage: python tools/pmc_summary.py traffic <fetch_csv> <write_csv> <out.json>
+       python tools/pmc_summary.py sq2 <sq_csv> <f64mix_csv> <out.json> [forwards=20]   (round 2: adds VALU issue fraction and the
+                                                                                            f64 instruction mix -> flops per env step)
        python tools/pmc_summary.py sq <sq_csv> <out.json> [forwards_per_launch_per_wave=20]
 Only launches of sumo_step_kernel are used; the first `skip` launches (warm-up) are dropped."""
 import csv, json, sys
 from collections import defaultdict
 
 
-def per_launch(path, kernel_sub="sumo_step_kernel", skip=5):
+KSUB = "sumo_step_kernel"       # overridden by a trailing `kernel=<substring>` argument; `steps=<K>`: env steps per env per launch
+KSTEPS = 1
+KENVS = 0
+for _a in list(sys.argv):
+    if _a.startswith("envs="):
+        KENVS = int(_a.split("=", 1)[1]); sys.argv.remove(_a)
+for _a in list(sys.argv):
+    if _a.startswith("kernel="):
+        KSUB = _a.split("=", 1)[1]; sys.argv.remove(_a)
+    elif _a.startswith("steps="):
+        KSTEPS = int(_a.split("=", 1)[1]); sys.argv.remove(_a)
+
+
+def per_launch(path, kernel_sub=None, skip=None):
+    kernel_sub = kernel_sub or KSUB
+    skip = (5 if KSUB == "sumo_step_kernel" else 1) if skip is None else skip
     vals = defaultdict(lambda: defaultdict(float))    # counter -> dispatch -> value (summed over XCD/SE rows)
     name = None; grid = None
     for r in csv.DictReader(open(path)):
@@ -32,7 +49,9 @@ if sys.argv[1] == "traffic":
         if n <= 4096 and n + (n + 63) // 64 == wgs:
             envs = n
             break
-    res = {"kernel": name, "envs": envs, "workgroups": wgs, "launches_averaged": [nf, nw],
+    envs = KENVS or envs
+    res = {"kernel": name, "envs": envs, "env_steps_per_env_per_launch": KSTEPS, "workgroups": wgs, "launches_averaged": [nf, nw],
+           "traffic_bytes_per_env_step": (fk * 1024 * 2 + wk * 1024) / (envs * KSTEPS),
            "FETCH_SIZE_kb_per_launch": fk, "WRITE_SIZE_kb_per_launch": wk,
            "fetch_bytes_corrected_x2": fk * 1024 * 2, "write_bytes": wk * 1024,
            "traffic_bytes_per_launch": fk * 1024 * 2 + wk * 1024,
@@ -40,6 +59,43 @@ if sys.argv[1] == "traffic":
                      "--warmup 5 --no-cpu-baseline; bytes = counter * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
                      "reports half of a coalesced stream; calibrated there for 16 B/lane loads, this kernel issues 8 B/lane record "
                      "reads, so treat the read side as approximate)"}
+    json.dump(res, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps(res, indent=1))
+elif sys.argv[1] == "sq2":
+    name, grid, s = per_launch(sys.argv[2]); _, _, m = per_launch(sys.argv[3])
+    fw = float(sys.argv[5]) if len(sys.argv) > 5 else 20.0
+    wgs = grid // 64
+    envs = wgs
+    for n in range(wgs, 0, -1):
+        if n <= 4096 and n + (n + 63) // 64 == wgs:
+            envs = n
+            break
+    envs = (KENVS or envs) * KSTEPS          # env steps per launch: every per-"wave" figure below is per env step
+    avg = {k: v[0] for k, v in s.items()}
+    mix = {k: v[0] for k, v in m.items()}
+    d = {}
+    d["valu_insts_per_forward_per_wave"] = avg["SQ_INSTS_VALU"] / envs / fw
+    d["salu_insts_per_forward_per_wave"] = avg["SQ_INSTS_SALU"] / envs / fw
+    d["lds_insts_per_forward_per_wave"] = avg["SQ_INSTS_LDS"] / envs / fw
+    d["wave_cycles_per_forward"] = avg["SQ_WAVE_CYCLES"] / envs / fw * 4            # SQ_WAVE_CYCLES counts quad-cycles (MI355X_MICROARCH.md)
+    for k, nm in (("SQ_ACTIVE_INST_VALU", "active_valu_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_any_frac"), ("SQ_WAIT_ANY", "wait_any_frac")):
+        if k in avg: d[nm] = avg[k] / avg["SQ_WAVE_CYCLES"]
+    # kernel cycles: GRBM_GUI_ACTIVE is summed over the 8 XCDs by rocprofv3
+    kcyc = avg["GRBM_GUI_ACTIVE"] / 8.0
+    d["kernel_cycles"] = kcyc
+    d["valu_issue_frac"] = avg["SQ_INSTS_VALU"] * 4.0 / (256 * 4 * kcyc)               # 4 issue cycles per wave64 VALU op, 1024 SIMDs
+    if "SQ_THREAD_CYCLES_VALU" in mix and "SQ_ACTIVE_INST_VALU" in mix and mix["SQ_ACTIVE_INST_VALU"] > 0:
+        d["mean_active_lanes"] = mix["SQ_THREAD_CYCLES_VALU"] / mix["SQ_ACTIVE_INST_VALU"]   # both in the same (quad-cycle) unit: counter_defs.yaml ratio
+    f64 = {k: mix.get("SQ_INSTS_VALU_%s_F64" % k, 0.0) for k in ("ADD", "MUL", "FMA", "TRANS")}
+    d["f64_wave_insts_per_env_step"] = {k: v / envs for k, v in f64.items()}
+    d["f64_flops_issued_per_env_step"] = (f64["ADD"] + f64["MUL"] + f64["TRANS"] + 2.0 * f64["FMA"]) * 64.0 / envs
+    d["f64_share_of_valu_insts"] = sum(f64.values()) / mix["SQ_INSTS_VALU"] if mix.get("SQ_INSTS_VALU") else None
+    res = {"kernel": name, "envs": envs // KSTEPS, "env_steps_per_env_per_launch": KSTEPS, "workgroups": wgs,
+           "counters_avg_per_launch": dict(avg, **{"mix_" + k: v for k, v in mix.items()}),
+           "derived": d,
+           "method": "two rocprofv3 --pmc passes with --kernel-trace only over `bench.py --steps 10 --warmup 5 --no-cpu-baseline --ppo-nsteps 0 "
+                     "--spider-steps 0` (bench default: two env groups of 2048, serialised by the profiler); per-launch averages after 5 "
+                     "skipped launches; valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8)"}
     json.dump(res, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(res, indent=1))
 else:
