@@ -75,7 +75,7 @@ struct Layout {  // LDS offsets in doubles unless noted
   int xpos, xquat, xipos, gaxis, xanchor, xaxis, com, cinert, cdof, abuf, cfrc;  // "kin scratch"
   int H;                                                                           // aliases kin scratch
   int M, bias, qsm, asmo, Ma, grad, search, Mv, x, dlim;
-  int stash;     // 4 doubles parked across the step loop (+ 2 for the fused rollout's ticket)
+  int stash;     // 4 doubles parked across the step loop (+ 8 for the fused rollout: ticket, reward inputs, episode record, development clock)
   int cmask;     // per dof: 64-bit mask of the contacts whose Jacobian touches the dof
   int cond, Jb, cpar, cW, cp, jar, D, aref;
   int limD, limA;  // joint-limit slots, hinge-indexed: [nhinge] lower side | [nhinge] upper side (D = 0: side not active)
@@ -1903,7 +1903,26 @@ __device__ __forceinline__ void reset_state(C& c, uint64_t seed, uint32_t rc) {
 }
 
 // agents.py:190-214 (cfrc_ext == 0) + time feature (sumo_env.py:68-70)
-template <class C>
+// ---- coherent hand-over accessors -----------------------------------------------------------------------------------
+// In the fused rollout launch an env moves between waves (possibly on another XCD, whose L2 is not coherent with ours) from one
+// step to the next.  Only a few hundred bytes cross: the state record, the counters, the observations and the done flags.
+// They are written and read with agent-scope relaxed atomics -- `sc1` stores that write through to memory and `sc1` loads
+// that bypass the non-coherent cache levels (MI355X_MICROARCH.md, inter-workgroup visibility, the all-sc1 form) -- so no
+// L2 write-back / invalidate fence is needed per step: a release fence there flushes every dirty line of the XCD's L2,
+// scratch frames included, 2 million times a second (measured: 67 KB of HBM writes per env step against 2.5 KB algorithmic).
+// COH = false (per-step launch): plain accesses, the kernel boundary orders them.
+template <bool COH, class T>
+__device__ __forceinline__ T hand_load(const T* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool COH, class T>
+__device__ __forceinline__ void hand_store(T* p, T v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+template <bool COH = false, class C>
 __device__ __forceinline__ void write_obs(C& c, float* obs, int obs_stride, int num_steps) {
   const sumo_model_t& mdl = c.P->mdl;
   for (int idx = c.lane; idx < 2 * obs_stride; idx += WAVE) {
@@ -1917,7 +1936,7 @@ __device__ __forceinline__ void write_obs(C& c, float* obs, int obs_stride, int 
     else if (k < nqa + nva + 6 * nba + 7) v = (float)S(qpos)[MI(agent_qposadr)[o] + (k - nqa - nva - 6 * nba)];
     else if (k < dim - 1) v = 0.0f;
     else if (k == dim - 1) v = (float)(-1.0 + 2.0 * num_steps / 500.0);
-    obs[idx] = v;
+    hand_store<COH>(obs + idx, v);
   }
 }
 
@@ -1930,6 +1949,19 @@ __device__ __forceinline__ float sumsq_f32(const float* a, int n) {  // numpy fl
     for (int j = 0; j < 8; j++) r[j] += a[i + j] * a[i + j];
   float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
   for (; i < n; i++) res += a[i] * a[i];
+  return res;
+}
+
+// the same sum over the step's control vector in LDS (S(ctrl)[i] == (double)action[i] exactly: float -> double -> float)
+__device__ __forceinline__ float sumsq_f32_ctrl(const double* u, int n) {
+  if (n < 8) { float r = 0.0f; for (int i = 0; i < n; i++) { const float a = (float)u[i]; r += a * a; } return r; }
+  float r[8];
+  for (int j = 0; j < 8; j++) { const float a = (float)u[j]; r[j] = a * a; }
+  int i;
+  for (i = 8; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; j++) { const float a = (float)u[i + j]; r[j] += a * a; }
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; i++) { const float a = (float)u[i]; res += a * a; }
   return res;
 }
 
@@ -1975,21 +2007,21 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.tprev = clock64();
 #endif
 }
-template <class C>
+template <bool COH = false, class C>
 __device__ __forceinline__ void load_state(C& c, const StepArgs& a, int e) {
   const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
   const double* st = a.state + (size_t)e * a.state_stride;
   for (int i = lane; i < nq + 2 * nv; i += WAVE) {
-    double v = st[i];
+    double v = hand_load<COH>(st + i);
     if (i < nq) S(qpos)[i] = v; else if (i < nq + nv) S(qvel)[i - nq] = v; else S(warm)[i - nq - nv] = v;
   }
 }
-template <class C>
+template <bool COH = false, class C>
 __device__ __forceinline__ void store_state(C& c, const StepArgs& a, int e) {
   const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
   double* st = a.state + (size_t)e * a.state_stride;
   for (int i = lane; i < nq + 2 * nv; i += WAVE)
-    st[i] = i < nq ? S(qpos)[i] : (i < nq + nv ? S(qvel)[i - nq] : S(warm)[i - nq - nv]);
+    hand_store<COH>(st + i, i < nq ? S(qpos)[i] : (i < nq + nv ? S(qvel)[i - nq] : S(warm)[i - nq - nv]));
 }
 template <class C>
 __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
@@ -2043,13 +2075,13 @@ extern __shared__ double smem_dyn[];
 // observation write, state record back (the whole of SumoEnv._step + the wrappers + the worker's auto-reset:
 // sumo.py:120-202, sumo_env.py:40-72, monitor.py:51-78, subproc_vec_env.py:10-19).  Shared by the per-step launch
 // (sumo_step_kernel) and the fused multi-step rollout launch (sumo_rollout_kernel).
-template <class C>
+template <bool COH = false, class C>
 __device__ __forceinline__ void env_step_body(C& c, const StepArgs& a, int e) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane;
   if (a.trace && lane == 0) a.trace[4 * e] = wall_clock64();
-  load_state(c, a, e);
-  if (lane < mdl.nu) {
+  load_state<COH>(c, a, e);
+  if (!COH && lane < mdl.nu) {   // fused rollout: the policy phase has put the step's actions into S(ctrl) itself
     const float* act0 = a.actions + (size_t)e * 2 * a.act_stride;
     int ag = lane >= MI(agent_uadr)[1] ? 1 : 0;
     S(ctrl)[lane] = (double)act0[ag * a.act_stride + (lane - MI(agent_uadr)[ag])];
@@ -2067,11 +2099,10 @@ __device__ __forceinline__ void env_step_body(C& c, const StepArgs& a, int e) {
   // (nothing stays live for it: a skipped state is still bad when the exit half looks)
   if (!state_is_bad(c)) mj_steps(c, mdl.frame_skip);
   PROF(18);
-  const float* act = a.actions + (size_t)e * 2 * a.act_stride;
   int* cnt = a.counters + 4 * e;
-  int num_steps = cnt[0], reset_count = cnt[1];
+  int num_steps = hand_load<COH>(cnt), reset_count = hand_load<COH>(cnt + 1);
   double* st = a.state + (size_t)e * a.state_stride;
-  double ep_ret = st[mdl.nq + 2 * mdl.nv], ep_dense = st[mdl.nq + 2 * mdl.nv + 1];
+  double ep_ret = hand_load<COH>(st + mdl.nq + 2 * mdl.nv), ep_dense = hand_load<COH>(st + mdl.nq + 2 * mdl.nv + 1);
   double before[2][2] = {{S(stash)[0], S(stash)[1]}, {S(stash)[2], S(stash)[3]}};
   // ---- game rules (sumo.py:120-202), evaluated redundantly by every lane (wave-uniform result)
   double after[2][2], z[2];
@@ -2092,7 +2123,7 @@ __device__ __forceinline__ void env_step_body(C& c, const StepArgs& a, int e) {
 #pragma unroll
   for (int g = 0; g < 2; g++) {
     int o = 1 - g, flags = 0;
-    double ctrl_r = -0.1 * (double)sumsq_f32(act + g * a.act_stride, MI(agent_nu)[g]);
+    double ctrl_r = -0.1 * (double)sumsq_f32_ctrl(S(ctrl) + MI(agent_uadr)[g], MI(agent_nu)[g]);   // the actions as the step received them
     double lose = lost[g] ? -2000.0 : 0.0, win = lost[o] ? 2000.0 : 0.0;
     if (lost[g] || lost[o]) dn = 1;
     if (lost[o]) flags |= 1;
@@ -2130,18 +2161,27 @@ __device__ __forceinline__ void env_step_body(C& c, const StepArgs& a, int e) {
 #pragma unroll
     for (int g = 0; g < 2; g++)
 #pragma unroll
-      for (int k = 0; k < SUMO_INFO_STRIDE; k++) io[g * SUMO_INFO_STRIDE + k] = inf[g][k];
+      for (int k = 0; k < SUMO_INFO_STRIDE; k++) hand_store<COH>(io + g * SUMO_INFO_STRIDE + k, inf[g][k]);
+    if (COH) {   // what the rollout's post phase needs of this step stays in LDS (nothing written in a launch is read back from HBM)
+      double* sh = S(stash) + 5;
+      sh[0] = inf[0][6]; sh[1] = inf[0][3]; sh[2] = inf[1][6]; sh[3] = inf[1][3]; sh[4] = dn ? ep_ret : 0.0;
+      ((int*)(sh + 5))[0] = dn ? num_steps : 0; ((int*)(sh + 5))[1] = dn;
+    }
   }
-  if (lane < 2) a.done[2 * e + lane] = (uint8_t)dn;
-  if (lane == 0) { a.ep_r[e] = dn ? ep_ret : 0.0; a.ep_dr[e] = dn ? ep_dense : 0.0; a.ep_l[e] = dn ? num_steps : 0; }
+  // both agents' flags as one 16-bit store (one coherent store on the hand-over path)
+  if (lane == 0) hand_store<COH>((uint16_t*)(a.done + 2 * e), (uint16_t)(dn ? 0x0101 : 0));
+  if (lane == 0) { hand_store<COH>(a.ep_r + e, dn ? ep_ret : 0.0); hand_store<COH>(a.ep_dr + e, dn ? ep_dense : 0.0); hand_store<COH>(a.ep_l + e, dn ? num_steps : 0); }
   if (dn) {  // subproc_vec_env.py:13-16: auto-reset, reset observation replaces the terminal one
     reset_state(c, a.seeds[e], (uint32_t)reset_count);
     reset_count++;
     num_steps = 0; ep_ret = 0; ep_dense = 0;
   }
-  write_obs(c, a.obs + (size_t)e * 2 * a.obs_stride, a.obs_stride, num_steps);
-  store_state(c, a, e);
-  if (lane == 0) { cnt[0] = num_steps; cnt[1] = reset_count; st[mdl.nq + 2 * mdl.nv] = ep_ret; st[mdl.nq + 2 * mdl.nv + 1] = ep_dense; }
+  write_obs<COH>(c, a.obs + (size_t)e * 2 * a.obs_stride, a.obs_stride, num_steps);
+  store_state<COH>(c, a, e);
+  if (lane == 0) {
+    hand_store<COH>(cnt, num_steps); hand_store<COH>(cnt + 1, reset_count);
+    hand_store<COH>(st + mdl.nq + 2 * mdl.nv, ep_ret); hand_store<COH>(st + mdl.nq + 2 * mdl.nv + 1, ep_dense);
+  }
   PROF(19);
   // work estimate for the next launch's longest-first schedule (sumo_step): Newton iterations dominate the variation
   // (a contention-independent proxy; sorting by the measured cycle count of the previous step schedules no better)
@@ -2204,11 +2244,11 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const StepArgs& a, co
   // the env's two observations: into the tile and into the rollout record (runner.py:98-101)
   const float* ob = a.obs + (size_t)e * 2 * a.obs_stride;
   for (int k = lane; k < D; k += WAVE) {
-    const float o0 = ob[k], o1 = ob[a.obs_stride + k];
+    const float o0 = hand_load<true>(ob + k), o1 = hand_load<true>(ob + a.obs_stride + k);
     xbuf[k] = o0; xbuf[XS + k] = o1;
     r.obs[slot0 * D + k] = o0; r.obs[slot1 * D + k] = o1;
   }
-  if (lane < 2) r.done[lane == 0 ? slot0 : slot1] = a.done[2 * e + lane];
+  if (lane < 2) r.done[lane == 0 ? slot0 : slot1] = (uint8_t)(hand_load<true>((const uint16_t*)(a.done + 2 * e)) >> (8 * lane));
   wave_sync();
   const float* lp = r.learner;
   const float* op = r.opponent + (size_t)(r.opp_idx ? r.opp_idx[e] : 0) * r.L.P;
@@ -2233,7 +2273,9 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const StepArgs& a, co
   if (ok) {
     r.act[slot0 * A + i] = act0; r.act[slot1 * A + i] = act1;
     float* ae = const_cast<float*>(a.actions) + (size_t)e * 2 * a.act_stride;
-    ae[i] = act0; ae[a.act_stride + i] = act1;
+    hand_store<true>(ae + i, act0); hand_store<true>(ae + a.act_stride + i, act1);     // the env's action buffer (output only)
+    const sumo_model_t& mdl = c.P->mdl;
+    S(ctrl)[MI(agent_uadr)[0] + i] = (double)act0; S(ctrl)[MI(agent_uadr)[1] + i] = (double)act1;   // the step's control vector
   }
   if (lane == 0) {
     r.nlp[slot0] = nlp0; r.nlp[slot1] = nlp1; r.onlp[slot0] = onlp0; r.onlp[slot1] = onlp1;
@@ -2244,15 +2286,16 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const StepArgs& a, co
 
 template <class C>
 __device__ __forceinline__ void rollout_post_phase(C& c, const StepArgs& a, const RolloutArgs& r, int e, int s) {
-  wave_sync();   // info / done / episode records of the step were written by other lanes
+  SYNC();   // the step's reward inputs and episode record were parked in LDS by lane 0 of the epilogue
   const int lane = c.lane;
   const size_t col = (size_t)r.env_offset + e;
   if (lane < 2) {   // runner.py:134 + monitor.py:63-78 harvest, as ppo_post_step_kernel
-    const double* I = a.info + (size_t)(2 * e + lane) * SUMO_INFO_STRIDE;
-    r.rew[((size_t)lane * r.T + s) * r.Ntot + col] = reward_mix(r.alpha, I[6], I[3]);
+    const double* sh = S(stash) + 5;
+    r.rew[((size_t)lane * r.T + s) * r.Ntot + col] = reward_mix(r.alpha, sh[2 * lane], sh[2 * lane + 1]);
     if (lane == 0) {
       const size_t t = (size_t)s * r.Ntot + col;
-      r.ep_done[t] = a.done[2 * e]; r.ep_r[t] = a.ep_r[e]; r.ep_l[t] = a.ep_l[e];
+      const int* rec = (const int*)(sh + 5);
+      r.ep_done[t] = (uint8_t)rec[1]; r.ep_r[t] = sh[4]; r.ep_l[t] = rec[0];
     }
   }
 }
@@ -2269,9 +2312,9 @@ struct RolloutLaunch { StepArgs a; RolloutArgs r; };
 // its env's previous step: prog[e] counts the finished steps of env e, the wave that draws (e, k) waits for prog[e] == k
 // (rarely: that ticket was handed out N tickets earlier).  Dependencies only point to earlier tickets, which are held by waves
 // that are already running, so the scheme cannot deadlock whatever the number of resident waves; every wave leaves when the
-// tickets run out.  Hand-over of an env between waves goes through HBM: agent-scope release after the step's stores, relaxed
-// store of prog[e]; the next wave polls prog[e] with one lane and acquires at agent scope before its plain loads
-// (MI355X_MICROARCH.md, inter-workgroup visibility).  The wait is bounded: a wave that saw no progress for ~2 s raises the
+// tickets run out.  Hand-over of an env between waves: the few hundred bytes that cross (hand_load / hand_store above) go
+// through sc1 accesses, the writer drains them (s_waitcnt vmcnt(0)) before its relaxed agent-scope store of prog[e], the
+// next wave polls prog[e] with one lane and then reads the record with sc1 loads.  The wait is bounded: a wave that saw no progress for ~2 s raises the
 // launch's abort flag (counted in sumo_stats[9]) and every wave drains.
 #define ROLLOUT_SPIN_LIMIT (1u << 22)   /* polls of ~0.5 us each */
 
@@ -2301,18 +2344,21 @@ sumo_rollout_kernel(const Params* P, const RolloutLaunch* LP) {
       }
       ok = __builtin_amdgcn_readfirstlane(ok);
       if (!ok) { if (c.lane == 0 && lp->a.stats) atomicAdd(lp->a.stats + 9, 1ull); break; }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("" ::: "memory");   // the env's record is read after the poll, through sc1 loads (hand_load): nothing to invalidate
     }
     // (e, k) wait in LDS during the phases (nothing but the context stays live across the forward-dynamics evaluations)
     if (c.lane == 0) { int* tk = (int*)(S(stash) + 4); tk[0] = e; tk[1] = k; }
     lp = launder_sptr(LP);
     int s = lp->r.s0 + k;
+    // development (sumo_debug_trace): per-env phase clock, accumulated with atomics (an env's steps run on many waves);
+    // the caller zeroes the buffer: [4e] first start, [4e+1] last end, [4e+2] ticks in policy phases, [4e+3] ticks in env steps
     unsigned long long* prof = lp->r.prof;
-    if (prof && c.lane == 0) { const unsigned long long tk = wall_clock64(); if (k == 0) { prof[4 * e] = tk; prof[4 * e + 2] = 0; prof[4 * e + 3] = 0; } prof[4 * e + 2] -= tk; }
+    unsigned long long t0 = 0;
+    if (prof && c.lane == 0) { t0 = wall_clock64(); if (k == 0) atomicExch(prof + 4 * e, t0); }
     rollout_policy_phase(c, lp->a, lp->r, e, s);
     prof = launder_sptr(LP)->r.prof;
-    if (prof && c.lane == 0) { const unsigned long long tk = wall_clock64(); prof[4 * e + 2] += tk; prof[4 * e + 3] -= tk; }
-    env_step_body(c, launder_sptr(LP)->a, e);
+    if (prof && c.lane == 0) { const unsigned long long t1 = wall_clock64(); atomicAdd(prof + 4 * e + 2, t1 - t0); S(stash)[11] = __longlong_as_double((long long)t1); }
+    env_step_body<true>(c, launder_sptr(LP)->a, e);
     SYNC();
     { const int* tk = (const int*)(S(stash) + 4); e = __builtin_amdgcn_readfirstlane(tk[0]); k = __builtin_amdgcn_readfirstlane(tk[1]); }
     asm volatile("" : "+s"(e), "+s"(k));
@@ -2320,9 +2366,12 @@ sumo_rollout_kernel(const Params* P, const RolloutLaunch* LP) {
     s = lp->r.s0 + k;
     rollout_post_phase(c, lp->a, lp->r, e, s);
     prof = lp->r.prof;
-    if (prof && c.lane == 0) { const unsigned long long tk = wall_clock64(); prof[4 * e + 3] += tk; prof[4 * e + 1] = tk; }
-    // hand the env over: all of this wave's stores of the step, then the progress counter
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (prof && c.lane == 0) {
+      const unsigned long long t2 = wall_clock64(), t1 = (unsigned long long)__double_as_longlong(S(stash)[11]);
+      atomicAdd(prof + 4 * e + 3, t2 - t1); atomicMax(prof + 4 * e + 1, t2);
+    }
+    // hand the env over: every sc1 store of the step has reached memory (vmcnt = 0), then the progress counter
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (c.lane == 0) __hip_atomic_store(launder_sptr(LP)->r.sched + 2 + e, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   flush_stats(c, launder_sptr(LP)->a.stats);
@@ -2789,7 +2838,7 @@ static void build_layout(sumo_engine* E) {
   }
   L.qsm = take(nv); L.asmo = take(nv); L.Ma = 0; L.grad = 0;
   L.search = take(nv); L.bias = L.search;   // the bias force is consumed (into qsm) before the solver writes its search direction
-  L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv); L.stash = take(6);   // + the fused rollout's (env, step) of the ticket in flight
+  L.Mv = 0; L.x = take(nv); L.dlim = take(nv); L.cmask = take(nv); L.stash = take(12);   // + the fused rollout's ticket (env, step) and the step's reward inputs / episode record for its post phase
   // contact records live from the narrow phase to the Jacobian build only: they borrow the mass matrix's storage
   if (L.msize < 14 * L.maxcon) L.msize = 14 * L.maxcon;
   if (L.msize < 12 * nb) L.msize = 12 * nb;      // ... and so do the velocity-pass temporaries (abuf, cfrc), see below

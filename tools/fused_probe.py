@@ -41,7 +41,7 @@ for cfg in a.configs.split(","):
     if fused and groups == 1:
         stamps = torch.zeros((a.envs, 4), dtype=torch.int64, device=env.device)
         env.engine.debug_trace(stamps.data_ptr())
-        run(); torch.cuda.synchronize()
+        run(); torch.cuda.synchronize()   # (one launch: chunk = steps)
         env.engine.debug_trace(None)
         st = stamps.cpu().numpy().astype(np.int64)
         pol = st[:, 2] / 1e5; envt = st[:, 3] / 1e5
