@@ -79,6 +79,16 @@ int ppo_lstm_step(const ppo_lstm_net* net, const float* obs, int n, int obs_stri
                   int state_stride, const float* noise, const float* given_action, float* action_out, float* neglogp_out,
                   float* value_out, float* mean_out, void* stream);
 
+/* ppo_lstm_step against a POOL of frozen nets (BASELINE config 5: 16 opponent snapshots, one per env tile; the reference loads one
+ * snapshot for all envs per update, alg_ppo.py:213-214): rows 16 t .. 16 t + 15 are evaluated with nets_dev[tile_net_dev[t]].
+ * `proto` (host) gives the dimensions / gate order every net of the pool shares and is checked like ppo_lstm_step's net;
+ * nets_dev is a DEVICE array of ppo_lstm_net whose pointers address each snapshot's weights, tile_net_dev DEVICE int32
+ * [ceil(n / 16)].  Everything else as ppo_lstm_step (one launch for all tiles). */
+int ppo_lstm_step_pool(const ppo_lstm_net* proto, const ppo_lstm_net* nets_dev, const int32_t* tile_net_dev, const float* obs, int n,
+                       int obs_stride, const float* mask, float* c, float* h, int state_stride, const float* noise,
+                       const float* given_action, float* action_out, float* neglogp_out, float* value_out, float* mean_out,
+                       void* stream);
+
 /* --- recurrent training (back-propagation through time over the baselines LSTM; the reference builds the unrolled graph in
  * a2c/utils.py:82-103 + model.py:65-139, its own recurrent minibatch loop alg_ppo.py:408-421 is dead code) ---------------
  * ppo_lstm_step_save: ppo_lstm_step that also records what the backward pass needs for this time step:

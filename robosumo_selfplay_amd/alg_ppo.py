@@ -88,7 +88,7 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
           ent_coef=0.0, lr=3e-4, vf_coef=0.5, max_grad_norm=0.5, gamma=0.99, lam=0.95, rho_bar=1.0, c_bar=1.0, log_interval=10,
           nminibatches=4, noptepochs=4, cliprange=0.2, save_interval=1, load_path=None, model_fn=None, update_fn=None, init_fn=None,
           nagent=1, anneal_bound=500, vgap=None, kl_threshold=None, neglogp_threshold=10000.0, log_dir=None, comm=None,
-          verbose=True, fix_opponent_path=None, **network_kwargs):
+          verbose=True, fix_opponent_path=None, opponent_pool=1, **network_kwargs):
     import torch
     if seed is not None:                                                # set_global_seeds (misc_util.py:48-62)
         np.random.seed(seed)
@@ -133,6 +133,23 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         m.act_model.seed((seed or 0) * 1000 + 17 * i + rank)
     runner = Runner(env=env, models=models, nsteps=nsteps, nagent=nagent, gamma=gamma, lam=lam, rho_bar=rho_bar, c_bar=c_bar,
                     anneal_bound=anneal_bound)
+    # opponent_pool = K > 1 (extension, BASELINE config 5): K frozen snapshots stay resident in HBM and every env plays against its own
+    # one (opponent_pool.py); each update draws K snapshots by the selection law of ``opponent_mode`` instead of one.  K = 1 is the
+    # reference: one snapshot for all parallel envs (alg_ppo.py:213-214).
+    pool = None
+    opp_ref = models[1] if nagent > 1 else None      # the single-snapshot opponent model (reference of the 'ours' selector under a pool)
+    if int(opponent_pool) > 1:
+        if opponent_mode == "fix":
+            raise ValueError("opponent_pool > 1 makes no sense with a fixed opponent")
+        from .opponent_pool import LstmOpponentPool, OpponentPool
+        pool = (LstmOpponentPool if recurrent else OpponentPool)(policy, int(opponent_pool), nenvs, dev)
+        if recurrent:
+            pool.seed((seed or 0) * 1000 + 17 + rank)
+            runner.models[1] = pool           # acts for agent 1 and scores agent 0's actions, each env tile with its own snapshot
+        else:
+            if not runner.fused_ok():
+                raise NotImplementedError("opponent_pool > 1 with MLP policies runs inside the fused rollout launch (SUMO_FUSED_ROLLOUT != 0)")
+            runner.opponent_pool = pool
     epinfobuf = deque(maxlen=100)
     shuffle_gen = torch.Generator(device=dev)
     shuffle_gen.manual_seed((seed or 0) * 7919 + 13)          # same minibatch order on every rank (equal shards)
@@ -140,7 +157,7 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         init_fn()
     tfirststart = time.perf_counter()
     history = dict(version_gap=[], off_policy_ratio_mean=[], off_env_ratio_mean=[], total_ratio_mean=[], off_policy_ratio_clip_frac=[],
-                   off_env_ratio_clip_frac=[], total_ratio_clip_frac=[], useful_ratio=[], ppo_clip_frac=[],
+                   off_env_ratio_clip_frac=[], total_ratio_clip_frac=[], useful_ratio=[], opponent_versions=[], ppo_clip_frac=[],
                    approxkl=[], early_stop_info=[], lossvals=[], fps=[], rollout_s=[], update_s=[])
     nupdates = total_timesteps // nbatch
     idx_choice = 0
@@ -161,31 +178,47 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
                 zoo.seed((seed or 0) * 1000 + 17 + rank)
                 runner.models[1] = FixedOpponentModel(zoo)
         elif update == 1:
-            runner.models[1].load(osp.join(checkdir, "00000"))
+            if not (recurrent and pool is not None):
+                runner.models[1].load(osp.join(checkdir, "00000"))
+            if pool is not None:
+                pool.set_snapshot(0, osp.join(checkdir, "00000"))
+                pool.assign_round_robin([0])
             history["version_gap"].append(0)
+            history["opponent_versions"].append([0])
         else:
             paths = sorted(osp.join(checkdir, f) for f in os.listdir(checkdir))
+            K = pool.capacity if pool is not None else 1
             if opponent_mode == "random":
-                idx_choice = int(np.random.choice(update, 1)[0])
-                history["version_gap"].append(update - 1 - idx_choice)
+                choices = [int(x) for x in np.random.choice(update, K)]
+                history["version_gap"].append(update - 1 - choices[0])
             elif opponent_mode == "latest":
-                idx_choice = len(paths) - 1
+                choices = list(range(len(paths) - 1, max(-1, len(paths) - 1 - K), -1))
             elif opponent_mode == "ours":                                # ratio-divergence sampling (:227-244)
-                ap = runner.models[1].act_model.action_probability(opponent_obs, given_action=opponent_actions)
+                ref = opp_ref if (recurrent and pool is not None) else runner.models[1]
+                ap = ref.act_model.action_probability(opponent_obs, given_action=opponent_actions)
                 sub = np.sort(np.random.choice(len(paths), 30, replace=False)) if len(paths) > 30 else np.arange(len(paths))
                 naps = []
                 for i in sub:
                     model_util.load(paths[i])
                     naps.append(model_util.act_model.action_probability(opponent_obs, given_action=opponent_actions))
                 rd = selection_probs(ap, naps)
-                idx_choice = int(sub[np.random.choice(len(rd), 1, p=rd)[0]])
+                choices = [int(sub[j]) for j in np.random.choice(len(rd), K, p=rd)]
             else:
                 raise ValueError("opponent_mode %r" % (opponent_mode,))
-            if comm is not None:
-                c = torch.tensor([idx_choice], device=dev)
+            if comm is not None:                                         # rank 0 decides, everyone loads the same files
+                c = torch.tensor(choices + [-1] * (K - len(choices)), device=dev)
                 torch.distributed.broadcast(c, 0, group=comm)
-                idx_choice = int(c.item())
-            runner.models[1].load(paths[idx_choice])
+                choices = [int(x) for x in c.tolist() if x >= 0]
+            idx_choice = choices[0]
+            history["opponent_versions"].append(list(choices))
+            if recurrent and pool is not None:
+                opp_ref.load(paths[idx_choice])                          # reference opponent of the 'ours' selector
+            else:
+                runner.models[1].load(paths[idx_choice])
+            if pool is not None:
+                for k, ci in enumerate(choices):
+                    pool.set_snapshot(k, paths[ci])
+                pool.assign_round_robin(range(len(choices)))
         # ---- rollout
         obs, returns, masks, actions, values, neglogpacs, rewards, opponent_neglogpacs, opp_obs_s, opp_act_s, states, epinfos, \
             off_policy_ratio, off_env_ratio, total_ratio = runner.run(update)

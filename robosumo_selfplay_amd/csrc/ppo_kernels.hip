@@ -282,6 +282,8 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 struct LstmArgs {
   ppo_lstm_net net;
+  const ppo_lstm_net* pool;   // opponent pool: device array of nets (same dimensions as `net`) ...
+  const int32_t* tile_net;    // ... and the net each 16-row tile is evaluated with (NULL pool: `net` for every tile)
   const float *obs, *mask, *noise, *given;
   float *c, *h, *action, *neglogp, *value, *mean;
   float *sv_gates, *sv_cprev, *sv_hprev, *sv_tanhc;   // training: per-step records for the backward pass (all or none)
@@ -294,7 +296,7 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
   // update and their slice of the new latent -- so the serial chain per wave is a quarter of the tile's (one wave per tile
   // took 150 us for H = 128 whatever the batch: 63 dependent k-steps of 32 products, then 128 units of transcendentals).
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r0 = blockIdx.x * 16;
-  const ppo_lstm_net& N = a.net;
+  const ppo_lstm_net N = a.pool ? a.pool[a.tile_net[blockIdx.x]] : a.net;
   const int D = N.ob_dim, E = N.emb_dim, A = N.ac_dim, XS = a.XS, HP = a.HP;
   float* xbuf = smem_f;
   float* ebuf = xbuf + 16 * XS;
@@ -467,7 +469,7 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
 static int lstm_launch(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
                        int state_stride, const float* noise, const float* given_action, float* action_out, float* neglogp_out,
                        float* value_out, float* mean_out, float* sv_gates, float* sv_cprev, float* sv_hprev, float* sv_tanhc,
-                       void* stream) {
+                       void* stream, const ppo_lstm_net* pool_dev = nullptr, const int32_t* tile_net_dev = nullptr) {
   if (!net || !obs || !c || !h || n <= 0) FAIL(-1, "bad arguments");
   if (net->hidden != 64 && net->hidden != 128) FAIL(-2, "hidden %d: only 64 and 128 are built", net->hidden);
   if (net->ob_dim < 1 || net->ob_dim > 512 || obs_stride < net->ob_dim) FAIL(-3, "bad ob_dim/obs_stride");
@@ -477,6 +479,7 @@ static int lstm_launch(const ppo_lstm_net* net, const float* obs, int n, int obs
   if ((net->obs_mean == nullptr) != (net->obs_invstd == nullptr)) FAIL(-7, "obs_mean and obs_invstd must be given together");
   if (state_stride < net->hidden) FAIL(-8, "state_stride < hidden");
   LstmArgs a;
+  a.pool = pool_dev; a.tile_net = tile_net_dev;
   a.net = *net; a.obs = obs; a.mask = mask; a.noise = noise; a.given = given_action; a.c = c; a.h = h; a.action = action_out;
   a.neglogp = neglogp_out; a.value = value_out; a.mean = mean_out; a.n = n; a.obs_stride = obs_stride; a.state_stride = state_stride;
   a.sv_gates = sv_gates; a.sv_cprev = sv_cprev; a.sv_hprev = sv_hprev; a.sv_tanhc = sv_tanhc;
@@ -499,6 +502,14 @@ extern "C" int ppo_lstm_step(const ppo_lstm_net* net, const float* obs, int n, i
                              float* neglogp_out, float* value_out, float* mean_out, void* stream) {
   return lstm_launch(net, obs, n, obs_stride, mask, c, h, state_stride, noise, given_action, action_out, neglogp_out, value_out, mean_out,
                      nullptr, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int ppo_lstm_step_pool(const ppo_lstm_net* proto, const ppo_lstm_net* nets_dev, const int32_t* tile_net_dev, const float* obs, int n,
+                                  int obs_stride, const float* mask, float* c, float* h, int state_stride, const float* noise,
+                                  const float* given_action, float* action_out, float* neglogp_out, float* value_out, float* mean_out,
+                                  void* stream) {
+  if (!nets_dev || !tile_net_dev) FAIL(-1, "bad arguments");
+  return lstm_launch(proto, obs, n, obs_stride, mask, c, h, state_stride, noise, given_action, action_out, neglogp_out, value_out, mean_out,
+                     nullptr, nullptr, nullptr, nullptr, stream, nets_dev, tile_net_dev);
 }
 extern "C" int ppo_lstm_step_save(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
                                   int state_stride, float* save_gates, float* save_cprev, float* save_hprev, float* save_tanhc,

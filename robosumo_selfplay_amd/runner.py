@@ -233,8 +233,9 @@ class Runner(AbstractEnvRunner):
             a0, v0, S0, n0 = m0.step(o0, S=self.states[0][sl], M=dn[:, 0])
             self.states[0][sl] = S0
             act0.copy_(a0); B["val"][0, s, sl].copy_(v0); B["nlp"][0, s, sl].copy_(n0)
-            B["onlp"][0, s, sl].copy_(m1.act_model.action_probability(o0, given_action=a0))
-            a1, _, S1, on1 = m1.step(o1, S=self.states[1][sl], M=dn[:, 1])
+            pk = dict(first_env=sl.start) if hasattr(m1, "tile_net") else {}      # opponent pool: snapshots are indexed per env tile
+            B["onlp"][0, s, sl].copy_(m1.act_model.action_probability(o0, given_action=a0, **pk))
+            a1, _, S1, on1 = m1.step(o1, S=self.states[1][sl], M=dn[:, 1], **pk)
             self.states[1][sl] = S1
             act1.copy_(a1); B["onlp"][1, s, sl].copy_(on1)
             B["val"][1, s, sl].copy_(m0.value(o1, S=S1, M=dn[:, 1]))

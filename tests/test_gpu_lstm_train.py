@@ -162,3 +162,109 @@ def test_device_and_host_recurrent_rollouts_agree():
         env.close()
     for a, b in zip(*outs):
         assert a.shape == b.shape and np.allclose(a, b, rtol=1e-5, atol=1e-6), np.abs(a - b).max()
+
+
+def test_lstm_pool_step_equals_per_snapshot_steps():
+    """ppo_lstm_step_pool (every 16-row tile evaluated with its own frozen snapshot, one launch) against ppo_lstm_step with each
+    snapshot on that snapshot's tiles: actions, values, neglogps and new states bit-identical."""
+    from robosumo_selfplay_amd.opponent_pool import LstmOpponentPool
+    D, A, H, n, K = 121, 8, 128, 96, 4
+    rng = np.random.default_rng(2)
+    spec = lstm_model.LstmSpec(D, A, H)
+    np.random.seed(9)
+    singles = []
+    pool = LstmOpponentPool(spec, K, n, torch.device("cuda", 0))
+    for k in range(3):
+        m = lstm_model.LstmPPOModel(policy=spec, nbatch_act=n, nsteps=4, trainable=False)
+        m.set_param_list([p + rng.normal(0, 0.05, p.shape).astype(np.float32) for p in m.get_param_list()])
+        singles.append(m)
+        pool.set_snapshot(k, m.get_param_list(), label="v%d" % k)
+    tiles = np.array([0, 2, 1, 1, 0, 2])
+    pool.assign(tiles)
+    assert np.array_equal(pool.counts(), [32, 32, 32, 0]) and np.array_equal(pool.index.cpu().numpy(), np.repeat(tiles, 16))
+    obs = torch.from_numpy(rng.normal(0, 1, (n, D)).astype(np.float32)).cuda()
+    S = torch.from_numpy(rng.normal(0, 0.5, (n, 2 * H)).astype(np.float32)).cuda()
+    M = torch.from_numpy((rng.random(n) < 0.3).astype(np.uint8)).cuda()
+    given = torch.from_numpy(rng.normal(0, 1, (n, A)).astype(np.float32)).cuda()
+    # scoring a given action (zero state, as the Runner's call) and a deterministic step with carried state
+    nlp_pool = pool.action_probability(obs, given_action=given)
+    a_pool, v_pool, S_pool, n_pool = pool.step(obs, S=S, M=M, deterministic=True)
+    # a group's slice (first_env) sees its own tiles
+    a_half, _, _, _ = pool.step(obs[48:], S=S[48:], M=M[48:], deterministic=True, first_env=48)
+    assert torch.equal(a_half, a_pool[48:])
+    for k, m in enumerate(singles):
+        rows = torch.from_numpy(np.nonzero(np.repeat(tiles, 16) == k)[0]).cuda()
+        nlp_k = m.action_probability(obs[rows], given_action=given[rows])
+        a_k, v_k, S_k, n_k = m.step(obs[rows], S=S[rows], M=M[rows], deterministic=True)
+        assert torch.equal(nlp_pool[rows], nlp_k) and torch.equal(a_pool[rows], a_k) and torch.equal(v_pool[rows], v_k)
+        assert torch.equal(S_pool[rows], S_k) and torch.equal(n_pool[rows], n_k)
+    with pytest.raises(ValueError):
+        pool.assign(np.full(6, 3))                         # slot 3 was never filled
+
+
+def test_config5_shard_pool_rollout_and_bptt_update_vs_oracle(tmp_path):
+    """BASELINE config 5 on its one-GPU shard: Ant-vs-Ant, 1024 envs, LSTM(128) learner, a pool of 16 frozen LSTM snapshots (one per
+    16-env tile), rollout in the device-mode recurrent Runner, then ONE whole-sequence minibatch update (128 env sequences x 32
+    steps) checked against the numpy BPTT + TF1-Adam restatement (oracle/ppo_oracle.py, finite-difference verified).
+    Tolerances: loss terms 1e-3 relative, parameters after the step 3e-5 absolute (float32 MFMA / hipBLASLt vs float64)."""
+    from robosumo_selfplay_amd import alg_ppo
+    from robosumo_selfplay_amd.opponent_pool import LstmOpponentPool
+    from robosumo_selfplay_amd.runner import Runner
+    N, T, H, K = 1024, 32, 128, 16
+    env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=N, seed=50, groups=2)
+    spec = lstm_model.LstmSpec(121, 8, H)
+    np.random.seed(4)
+    learner = lstm_model.LstmPPOModel(policy=spec, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, nbatch_act=N, nsteps=T)
+    learner.seed(7)
+    pool = LstmOpponentPool(spec, K, N, env.device)
+    rng = np.random.default_rng(3)
+    base = learner.get_param_list()
+    for k in range(K):
+        pool.set_snapshot(k, [p + rng.normal(0, 0.02, p.shape).astype(np.float32) for p in base], label="v%d" % k)
+    pool.assign_round_robin()
+    pool.seed(8)
+    assert (pool.counts() == 64).all()
+    r = Runner(env=env, models=[learner, pool], nsteps=T, nagent=2, gamma=0.995, lam=0.95, rho_bar=1.0, c_bar=1.0, anneal_bound=500)
+    assert r.device_mode and r.recurrent
+    obs, returns, masks, actions, values, nlp, rewards, onlp, _, _, states0, epinfos, opr, oer, tot = r.run(1)
+    torch.cuda.synchronize()
+    assert obs.shape == (2, N * T, 121) and torch.isfinite(returns).all() and torch.isfinite(nlp).all() and torch.isfinite(onlp).all()
+    assert env.stats()["diverged"] == 0
+    # envs of different tiles really faced different opponents: the opponent's neglogp of the learner's actions at step 0 uses the
+    # tile's snapshot -> equals a single-snapshot evaluation only on that snapshot's tiles
+    o0 = obs[0].reshape(N, T, 121)[:, 0].contiguous()
+    a0 = actions[0].reshape(N, T, 8)[:, 0].contiguous()
+    ref = lstm_model.LstmPPOModel(policy=spec, nbatch_act=N, nsteps=T, trainable=False)
+    ref.params.copy_(pool.params[3])
+    same = (ref.action_probability(o0, given_action=a0) == onlp[0].reshape(N, T)[:, 0])
+    assert same[pool.index == 3].all() and not same[pool.index != 3].all()
+    # one minibatch = 128 whole env sequences (nenvs / nminibatches = 1024 / 8), as learn() forms them
+    mbenv = np.sort(rng.choice(N, 128, replace=False))
+    flatinds = torch.from_numpy((mbenv[:, None] * T + np.arange(T)[None, :]).ravel()).cuda()
+    mb = lambda x: x[flatinds]
+    S0 = states0[torch.from_numpy(mbenv).cuda()]
+    pl = [p.copy() for p in learner.get_param_list()]
+    w = torch.ones(128 * T, dtype=torch.float32, device="cuda")
+    out = learner.train(3e-4, 0.2, mb(obs[0]), mb(returns[0]), mb(masks[0]), mb(actions[0]), mb(values[0]), mb(nlp[0]), None, w, S0, nsteps=T)
+    torch.cuda.synchronize()
+    cv = lambda x: x.cpu().numpy()
+    tm = lambda x: np.swapaxes(cv(mb(x)).reshape(128, T, *x.shape[1:]), 0, 1)            # env-major rows -> [T, n, ...]
+    advs = po.normalize_advantages(cv(mb(returns[0])), cv(mb(values[0]))).reshape(128, T)
+    loss, stats, grads, _ = po.lstm_ppo_loss_and_grads(pl, tm(obs[0]), tm(masks[0]).astype(np.float32), tm(actions[0]), np.swapaxes(advs, 0, 1),
+                                                       tm(returns[0]), tm(nlp[0]), np.ones((T, 128)), cv(S0), 0.2, 0.01, 0.5)
+    got = np.array([float(x) for x in out[:5]])
+    assert np.allclose(got[:2], stats[:2], rtol=1e-3, atol=1e-5), (got, stats)
+    assert abs(got[3]) < 1e-4 and got[4] == 0.0                      # on-policy first step: ratio 1 (the stored neglogp is the acting net's own)
+    gc, _ = po.clip_by_global_norm(grads, 0.5)
+    newp, _, _ = po.adam_step([p.astype(np.float64) for p in pl], gc, [np.zeros_like(g) for g in gc], [np.zeros_like(g) for g in gc], 1, 3e-4)
+    for name, a, b in zip(lstm_model.policies.LSTM_PARAM_NAMES, learner.get_param_list(), newp):
+        assert np.abs(a - b.reshape(a.shape)).max() < 3e-5, (name, np.abs(a - b.reshape(a.shape)).max())
+    env.close()
+    # and the whole thing through learn(): two updates, the second one draws its 16 snapshots from the checkpoint directory
+    env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=256, seed=51, groups=2)
+    model = alg_ppo.learn(network="lstm", env=env, seed=4, total_timesteps=256 * 8 * 3, nagent=2, log_dir=str(tmp_path), verbose=False, nsteps=8,
+                          nminibatches=4, noptepochs=1, lr=3e-4, gamma=0.995, lam=1.0, rho_bar=10.0, c_bar=1.0, opponent_mode="random",
+                          nlstm=128, anneal_bound=1000, opponent_pool=16)
+    assert len(model.history["opponent_versions"]) == 3 and len(model.history["opponent_versions"][2]) == 16
+    assert all(np.isfinite(l).all() for l in model.history["lossvals"]) and torch.isfinite(model.params).all()
+    env.close()

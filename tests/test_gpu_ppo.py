@@ -507,3 +507,40 @@ def test_rollout_kernel_opponent_pool_per_env():
         p = OpponentPool(policies.PolicySpec(121, 8, value_network="copy", activation="relu"), 4, N, DEV)
         p.set_snapshot(0, snaps[0])
         p.assign(np.full(N, 2))                           # empty slot
+
+
+def test_learn_with_opponent_pool_matches_glue_oracle(tmp_path):
+    """learn() with a device-resident pool of 4 snapshots (MLP, fused rollout) and opponent-data reuse: runs, draws 4 snapshots per
+    update from the checkpoint directory, and the batch it hands to the optimiser equals the numpy restatement of reference
+    alg_ppo.py:258-344 applied to the rollout it collected (ratio hygiene, usable rows, concat of agent-1 rows, weights)."""
+    from robosumo_selfplay_amd import alg_ppo
+    seen = {}
+    orig = alg_ppo.assemble_update_batch
+
+    def spy(obs, returns, masks, actions, values, neglogpacs, rewards, off_policy_ratio, total_ratio, **kw):
+        out = orig(obs, returns, masks, actions, values, neglogpacs, rewards, off_policy_ratio, total_ratio, **kw)
+        seen["in"] = [x.clone() for x in (obs, returns, masks, actions, values, neglogpacs, rewards, off_policy_ratio, total_ratio)]
+        seen["kw"], seen["out"] = kw, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+        return out
+    alg_ppo.assemble_update_batch = spy
+    try:
+        env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=64, seed=31)
+        model = alg_ppo.learn(network="mlp", env=env, seed=9, total_timesteps=64 * 16 * 3, nagent=2, log_dir=str(tmp_path), verbose=False, nsteps=16,
+                              nminibatches=4, noptepochs=2, lr=3e-4, gamma=0.995, lam=0.95, rho_bar=1.0, c_bar=1.0, opponent_mode="ours",
+                              use_opponent_data="both", neglogp_threshold=14.0, opponent_pool=4, value_network="copy", num_hidden=64,
+                              activation="relu")
+    finally:
+        alg_ppo.assemble_update_batch = orig
+    h = model.history
+    assert len(h["opponent_versions"]) == 3 and len(h["opponent_versions"][1]) == 4 and h["opponent_versions"][0] == [0]
+    assert all(np.isfinite(l).all() for l in h["lossvals"]) and env.stats()["rollout_aborts"] == 0
+    obs, returns, masks, actions, values, nlp, rewards, opr, tr = [x.cpu().numpy() for x in seen["in"]]
+    want = po.update_batch(obs, returns, masks, actions, values, nlp, rewards, opr, opr, tr, nbatch=64 * 16, rho_bar=1.0,
+                           neglogp_threshold=14.0, use_opponent_data="both")
+    got = seen["out"]
+    assert 0 < len(want["usable_index"]) < 64 * 16                      # the threshold really filters some opponent rows
+    assert np.array_equal(got["usable_index"].cpu().numpy(), want["usable_index"])
+    for k in ("obs", "returns", "actions", "values", "neglogpacs", "weights"):
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    assert abs(h["useful_ratio"][-1] - want["useful_ratio"]) < 1e-12
+    env.close()
