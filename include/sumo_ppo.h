@@ -109,6 +109,18 @@ int ppo_lstm_head_grad(const ppo_lstm_net* net, const float* latent, int rows, c
 int ppo_lstm_bwd_step(const ppo_lstm_net* net, int n, const float* dlatent_t, const float* mask_t, const float* gates_t,
                       const float* cprev_t, const float* tanhc_t, float* dh_carry, float* dc_carry, float* dz_out, void* stream);
 
+/* Weight gradients of the recurrent PPO step from the stored forward records and the deltas of the backward sweep (the matmuls
+ * TF's autodiff emits for a2c/utils.py:82-103 + the heads of policies.py:50,70): over all `rows` = (time, env) pairs,
+ *   [x | h_prev | 1]^T dz -> wx, wh, b      and      [latent | 1]^T [dmean | dvalue | dlogstd_rows] -> pi/w, pi/b, logstd, vf/w, vf/b
+ * written into `grads` in checkpoint order (wx | wh | b | pi/w | pi/b | logstd | vf/w | vf/b); logstd_shift is added to the
+ * logstd gradient (the entropy term - ent_coef / world).  x [rows][ob_dim], hprev / latent [rows][hidden], dz [rows][4 hidden],
+ * dmean / dlogstd_rows [rows][ac_dim], dvalue [rows].  Split-K MFMA kernel + fixed-order slab reduction (deterministic).
+ * workspace: ppo_lstm_wgrad_workspace_bytes(ob_dim, hidden, ac_dim) bytes. */
+size_t ppo_lstm_wgrad_workspace_bytes(int ob_dim, int hidden, int ac_dim);
+int ppo_lstm_wgrad(const ppo_lstm_net* net, int rows, const float* x, const float* hprev, const float* dz, const float* latent,
+                   const float* dmean, const float* dvalue, const float* dlogstd_rows, float logstd_shift, float* grads, void* workspace,
+                   void* stream);
+
 /* info float64 [n][2][8] as written by sumo_step (slot 6 shaping, slot 3 main); reward_out float32 [2][n]
  * (agent-major, one time slice of the rollout buffer) = alpha*shaping + (1-alpha)*main evaluated in float64. */
 int ppo_reward_mix(const double* info, int n, double alpha, float* reward_out, int agent_stride, void* stream);

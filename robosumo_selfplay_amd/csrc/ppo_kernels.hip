@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/sumo_ppo.h"
 
@@ -690,6 +691,143 @@ extern "C" int ppo_lstm_bwd_step(const ppo_lstm_net* net, int n, const float* dl
   else
     hipLaunchKernelGGL(ppo_lstm_bwd_step_kernel<128>, dim3(tiles), dim3(256), lds, (hipStream_t)stream, net->wh, n, dlatent_t, mask_t, gates_t,
                        cprev_t, tanhc_t, dh_carry, dc_carry, dz_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradients of the recurrent PPO step: C = A'^T B over all (time, env) rows of the minibatch, A' = [A0 | A1 | 1]
+// (input, previous hidden state, ones column for the bias), B = [B0 | B1 | B2] (gate / head deltas).  The contraction runs
+// over the ROWS (thousands), the output is small (250 x 512): split-K over workgroups -- every workgroup owns a chunk of rows,
+// each of its four waves a block of MT x NT output tiles held in MFMA accumulators (v_mfma_f32_16x16x4_f32: A operand =
+// 4 rows x 16 columns of A', B operand = 4 rows x 16 columns of B, both coalesced row reads) -- and one slab per chunk is
+// reduced in fixed order by a second kernel (deterministic, no float atomics: same scheme as ppo_grad).
+// ---------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* a_ptr[2]; int a_ld[2], a_cols[2]; int a_ones;   // A' columns: segment 0 | segment 1 | optional column of ones
+  const float* b_ptr[3]; int b_ld[3], b_cols[3];               // B columns: segment 0 | 1 | 2
+  int rows, rows_per_chunk, Mpad, Npad;
+  float* slabs;                                                // [chunks][Mpad][Npad]
+};
+
+__device__ __forceinline__ void wgrad_col(const float* const* ptr, const int* ld, const int* cols, int nseg, int ones, int col,
+                                          const float*& base, int& stride, float& cval) {
+  base = nullptr; stride = 0; cval = 0.0f;
+  int c = col;
+  for (int sgm = 0; sgm < nseg; sgm++) {
+    if (c < cols[sgm]) { if (ptr[sgm]) { base = ptr[sgm] + c; stride = ld[sgm]; } return; }
+    c -= cols[sgm];
+  }
+  if (ones && c == 0) cval = 1.0f;
+}
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) ppo_wgrad_kernel(WgradArgs a) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, i = lane & 15, kq = lane >> 4;
+  const int mt0 = (blockIdx.y * 4 + wid) * MT, nt0 = blockIdx.z * NT;
+  const int r_lo = blockIdx.x * a.rows_per_chunk, r_hi = min(a.rows, r_lo + a.rows_per_chunk);
+  const float* ap[MT]; int as[MT]; float ac[MT];
+  const float* bp[NT]; int bs[NT]; float bc[NT];
+#pragma unroll
+  for (int m = 0; m < MT; m++) wgrad_col(a.a_ptr, a.a_ld, a.a_cols, 2, a.a_ones, (mt0 + m) * 16 + i, ap[m], as[m], ac[m]);
+#pragma unroll
+  for (int n = 0; n < NT; n++) wgrad_col(a.b_ptr, a.b_ld, a.b_cols, 3, 0, (nt0 + n) * 16 + i, bp[n], bs[n], bc[n]);
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int n = 0; n < NT; n++) acc[m][n] = (f32x4){0, 0, 0, 0};
+  for (int r0 = r_lo; r0 < r_hi; r0 += 8) {            // two k-steps (8 rows) per trip: their operand loads are in flight together
+    float av[2][MT], bv[2][NT];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int row = r0 + 4 * u + kq;
+      const bool ok = row < r_hi;
+#pragma unroll
+      for (int m = 0; m < MT; m++) av[u][m] = ok ? (ap[m] ? ap[m][(size_t)row * as[m]] : ac[m]) : 0.0f;
+#pragma unroll
+      for (int n = 0; n < NT; n++) bv[u][n] = ok ? (bp[n] ? bp[n][(size_t)row * bs[n]] : bc[n]) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++) acc[m][n] = MFMA(av[u][m], bv[u][n], acc[m][n]);
+  }
+  // D layout: lane (i, kq) holds rows 4 kq + r (A' column index within the tile), column i (B column within the tile)
+  float* slab = a.slabs + (size_t)blockIdx.x * a.Mpad * a.Npad;
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = (mt0 + m) * 16 + 4 * kq + r, col = (nt0 + n) * 16 + i;
+        if (row < a.Mpad && col < a.Npad) slab[(size_t)row * a.Npad + col] = acc[m][n][r];
+      }
+}
+
+// fixed-order sum of the chunk slabs.  mode 0: dst[m][n] (leading dimension N) for m < M, n < N -- the LSTM's wx | wh | b
+// gradients are exactly the rows of [x | h_prev | 1]^T dz.  mode 1: the heads' gradients scattered into checkpoint order
+// pi/w [H][A] | pi/b [A] | logstd [A] | vf/w [H] | vf/b [1] from [latent | 1]^T [dmean (A) | dvalue (1) | dlogstd rows (A)];
+// `logstd_shift` (the entropy term, - ent_coef / world) is added to the logstd gradient.
+__global__ void __launch_bounds__(256) ppo_wgrad_reduce_kernel(const float* slabs, int chunks, int Mpad, int Npad, int M, int N, int mode, int Hh,
+                                                               int Aa, float logstd_shift, float* dst) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * N) return;
+  const int m = t / N, n = t - m * N;
+  float s = 0.0f;
+  for (int c = 0; c < chunks; c++) s += slabs[((size_t)c * Mpad + m) * Npad + n];
+  if (mode == 0) { dst[(size_t)m * N + n] = s; return; }
+  const int o_pw = 0, o_pb = Hh * Aa, o_ls = o_pb + Aa, o_vw = o_ls + Aa, o_vb = o_vw + Hh;
+  if (m < Hh) {
+    if (n < Aa) dst[o_pw + m * Aa + n] = s;
+    else if (n == Aa) dst[o_vw + m] = s;
+  } else {           // the ones row: column sums
+    if (n < Aa) dst[o_pb + n] = s;
+    else if (n == Aa) dst[o_vb] = s;
+    else dst[o_ls + (n - Aa - 1)] = s + logstd_shift;
+  }
+}
+
+extern "C" size_t ppo_lstm_wgrad_workspace_bytes(int ob_dim, int hidden, int ac_dim) {
+  const size_t Mp = (size_t)((ob_dim + hidden + 1 + 63) / 64) * 64, Np = (size_t)4 * hidden;
+  return (size_t)64 * Mp * Np * sizeof(float);     // 64 chunks at most; the head problem is smaller and reuses the buffer
+}
+
+extern "C" int ppo_lstm_wgrad(const ppo_lstm_net* net, int rows, const float* x, const float* hprev, const float* dz, const float* latent,
+                              const float* dmean, const float* dvalue, const float* dlogstd_rows, float logstd_shift, float* grads,
+                              void* workspace, void* stream) {
+  if (!net || !x || !hprev || !dz || !latent || !dmean || !dvalue || !dlogstd_rows || !grads || !workspace || rows <= 0) FAIL(-1, "bad arguments");
+  if (net->emb_w) FAIL(-2, "the baselines LSTM has no embedding layer");
+  const int D = net->ob_dim, Hh = net->hidden, Aa = net->ac_dim;
+  hipStream_t st = (hipStream_t)stream;
+  int chunks = (rows + 255) / 256;
+  if (chunks > 64) chunks = 64;
+  if (chunks < 1) chunks = 1;
+  int rpc = ((rows + chunks - 1) / chunks + 7) & ~7;
+  chunks = (rows + rpc - 1) / rpc;
+  {  // [x | h_prev | 1]^T dz  ->  wx | wh | b  (the first (D + H + 1) * 4H entries of the flat gradient, checkpoint order)
+    WgradArgs a = WgradArgs();
+    a.a_ptr[0] = x; a.a_ld[0] = D; a.a_cols[0] = D; a.a_ptr[1] = hprev; a.a_ld[1] = Hh; a.a_cols[1] = Hh; a.a_ones = 1;
+    a.b_ptr[0] = dz; a.b_ld[0] = 4 * Hh; a.b_cols[0] = 4 * Hh;
+    const int M = D + Hh + 1, N = 4 * Hh;
+    a.rows = rows; a.rows_per_chunk = rpc; a.Mpad = ((M + 63) / 64) * 64; a.Npad = N; a.slabs = (float*)workspace;
+    hipLaunchKernelGGL((ppo_wgrad_kernel<4, 8>), dim3(chunks, (a.Mpad + 255) / 256, (N + 127) / 128), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ppo_wgrad_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, a.slabs, chunks, a.Mpad, a.Npad, M, N, 0, Hh, Aa, 0.0f, grads);
+  }
+  {  // [latent | 1]^T [dmean | dvalue | dlogstd rows]  ->  pi/w | pi/b | logstd | vf/w | vf/b
+    WgradArgs a = WgradArgs();
+    a.a_ptr[0] = latent; a.a_ld[0] = Hh; a.a_cols[0] = Hh; a.a_cols[1] = 0; a.a_ones = 1;
+    a.b_ptr[0] = dmean; a.b_ld[0] = Aa; a.b_cols[0] = Aa; a.b_ptr[1] = dvalue; a.b_ld[1] = 1; a.b_cols[1] = 1;
+    a.b_ptr[2] = dlogstd_rows; a.b_ld[2] = Aa; a.b_cols[2] = Aa;
+    const int M = Hh + 1, N = 2 * Aa + 1;
+    a.rows = rows; a.rows_per_chunk = rpc; a.Mpad = ((M + 63) / 64) * 64; a.Npad = ((N + 31) / 32) * 32; a.slabs = (float*)workspace;
+    hipLaunchKernelGGL((ppo_wgrad_kernel<4, 2>), dim3(chunks, (a.Mpad + 255) / 256, a.Npad / 32), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ppo_wgrad_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, a.slabs, chunks, a.Mpad, a.Npad, M, N, 1, Hh, Aa, logstd_shift,
+                       grads + (size_t)(D + Hh + 1) * 4 * Hh);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -61,6 +61,8 @@ class LstmPPOModel(object):
             self.stats = torch.zeros(ppo_capi.NSTATS, dtype=torch.float64, device=self.device)
             self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
             self._graphs = {}
+            self.wgrad_native = os.environ.get("SUMO_LSTM_WGRAD", "native") != "blas"
+            self.wg_workspace = torch.empty(ppo_capi.lib().ppo_lstm_wgrad_workspace_bytes(D, H, A), dtype=torch.uint8, device=self.device)
 
     class _X:
         class dtype:
@@ -183,17 +185,23 @@ class LstmPPOModel(object):
         for k in range(T - 1, -1, -1):
             ppo_capi.chk(L.ppo_lstm_bwd_step(net, n, dlat[k].data_ptr(), Mk[k].data_ptr(), gates[k].data_ptr(), cprev[k].data_ptr(),
                                              tanhc[k].data_ptr(), dh.data_ptr(), dc.data_ptr(), dz[k].data_ptr(), st))
-        # weight gradients: plain GEMMs over all (time, env) rows
-        Z2, X2, H2, L2 = dz.view(rows, 4 * H), X.view(rows, D), hprev.view(rows, H), lat.view(rows, H)
-        g = self.gviews
-        t.matmul(X2.t(), Z2, out=g[0])
-        t.matmul(H2.t(), Z2, out=g[1])
-        t.sum(Z2, dim=0, out=g[2])
-        t.matmul(L2.t(), dmean, out=g[3])
-        t.sum(dmean, dim=0, out=g[4])
-        g[5].copy_((dls.sum(dim=0) - self.ent_coef / world).view(1, A))     # the entropy term once in the global sum
-        t.matmul(L2.t(), dvalue.view(rows, 1), out=g[6])
-        g[7].copy_(dvalue.sum().view(1))
+        # weight gradients: [x | h_prev | 1]^T dz and [latent | 1]^T [dmean | dvalue | dlogstd rows] over all (time, env) rows, on the
+        # split-K MFMA kernel (ppo_lstm_wgrad; SUMO_LSTM_WGRAD=blas keeps the library GEMMs for cross-checks)
+        if self.wgrad_native:
+            ppo_capi.chk(L.ppo_lstm_wgrad(net, rows, X.data_ptr(), hprev.data_ptr(), dz.data_ptr(), lat.data_ptr(), dmean.data_ptr(),
+                                          dvalue.data_ptr(), dls.data_ptr(), -self.ent_coef / world, self.grads.data_ptr(),
+                                          self.wg_workspace.data_ptr(), st))
+        else:
+            Z2, X2, H2, L2 = dz.view(rows, 4 * H), X.view(rows, D), hprev.view(rows, H), lat.view(rows, H)
+            g = self.gviews
+            t.matmul(X2.t(), Z2, out=g[0])
+            t.matmul(H2.t(), Z2, out=g[1])
+            t.sum(Z2, dim=0, out=g[2])
+            t.matmul(L2.t(), dmean, out=g[3])
+            t.sum(dmean, dim=0, out=g[4])
+            g[5].copy_((dls.sum(dim=0) - self.ent_coef / world).view(1, A))     # the entropy term once in the global sum
+            t.matmul(L2.t(), dvalue.view(rows, 1), out=g[6])
+            g[7].copy_(dvalue.sum().view(1))
         return state
 
     def _loss_step(self, cliprange, obs, ret, val, masks, actions, neglogpacs, IS_weight, states, T, world):

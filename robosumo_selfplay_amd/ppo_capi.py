@@ -9,7 +9,7 @@ FWD_PI, FWD_VF, FWD_TANH = 1, 2, 4
 LSTM_GATES_IFOU, LSTM_GATES_IJFO = 0, 1
 _LIB = None
 
-EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_forward_filtered", "ppo_lstm_step", "ppo_lstm_step_pool", "ppo_lstm_step_save", "ppo_lstm_head_grad", "ppo_lstm_bwd_step", "ppo_selfplay_forward", "ppo_post_step", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
+EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_forward_filtered", "ppo_lstm_step", "ppo_lstm_step_pool", "ppo_lstm_step_save", "ppo_lstm_head_grad", "ppo_lstm_bwd_step", "ppo_lstm_wgrad_workspace_bytes", "ppo_lstm_wgrad", "ppo_selfplay_forward", "ppo_post_step", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
            "ppo_adv_normalize", "ppo_grad_workspace_bytes", "ppo_grad", "ppo_clip_adam")
 
 
@@ -42,6 +42,9 @@ def lib():
         L.ppo_lstm_step_save.argtypes = [C.POINTER(LstmNet), vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.ppo_lstm_head_grad.argtypes = [C.POINTER(LstmNet), vp, i32, vp, vp, vp, vp, vp, f64, f32, f32, vp, vp, vp, vp, vp, vp]
         L.ppo_lstm_bwd_step.argtypes = [C.POINTER(LstmNet), i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.ppo_lstm_wgrad_workspace_bytes.argtypes = [i32, i32, i32]
+        L.ppo_lstm_wgrad_workspace_bytes.restype = C.c_size_t
+        L.ppo_lstm_wgrad.argtypes = [C.POINTER(LstmNet), i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp]
         L.ppo_reward_mix.argtypes = [vp, i32, f64, vp, i32, vp]
         L.ppo_selfplay_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), vp]
         L.ppo_post_step.argtypes = [vp, i32, f64, vp, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -53,7 +56,7 @@ def lib():
         L.ppo_grad.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, f64, f32, f32, f32, vp, vp, vp, vp, vp]
         L.ppo_clip_adam.argtypes = [vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, f64, vp, vp]
         for n in EXPORTS:
-            if n not in ("ppo_last_error", "ppo_grad_workspace_bytes"):
+            if n not in ("ppo_last_error", "ppo_grad_workspace_bytes", "ppo_lstm_wgrad_workspace_bytes"):
                 getattr(L, n).restype = i32
         _LIB = L
     return _LIB

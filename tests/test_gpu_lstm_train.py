@@ -268,3 +268,25 @@ def test_config5_shard_pool_rollout_and_bptt_update_vs_oracle(tmp_path):
     assert len(model.history["opponent_versions"]) == 3 and len(model.history["opponent_versions"][2]) == 16
     assert all(np.isfinite(l).all() for l in model.history["lossvals"]) and torch.isfinite(model.params).all()
     env.close()
+
+
+@pytest.mark.parametrize("T,n,D,A,H", [(5, 33, 121, 8, 128), (9, 40, 209, 16, 64), (3, 7, 13, 3, 64)])
+def test_native_weight_gradients_match_library_gemms(T, n, D, A, H):
+    """ppo_lstm_wgrad (split-K MFMA kernel + fixed-order slab reduction) against the same products through hipBLASLt
+    (SUMO_LSTM_WGRAD=blas path): every gradient tensor within 2e-5 of its scale (float32 summation order differs)."""
+    rng = np.random.default_rng(21)
+    obs, masks, actions, returns, values, S0 = _batch(rng, T, n, D, A, H)
+    flat = lambda x: np.ascontiguousarray(x).reshape(n * T, *x.shape[2:])
+    advs = rng.normal(0, 1, (n, T)).astype(np.float32)
+    old = rng.normal(4.0, 0.3, (n, T)).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, (n, T)).astype(np.float32)
+    res = []
+    for native in (True, False):
+        np.random.seed(1)
+        m = lstm_model.LstmPPOModel(policy=lstm_model.LstmSpec(D, A, H), ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, nbatch_act=n, nsteps=T)
+        m.wgrad_native = native
+        m.loss_and_grads(0.2, flat(obs), flat(returns), flat(masks), flat(actions), flat(advs), flat(old), flat(w), S0, T)
+        torch.cuda.synchronize()
+        res.append([g.cpu().numpy().astype(np.float64) for g in m.gviews])
+    for name, a, b in zip(lstm_model.policies.LSTM_PARAM_NAMES, *res):
+        assert a.shape == b.shape and np.abs(a - b).max() < 2e-5 * (np.abs(b).max() + 1e-6), (name, np.abs(a - b).max(), np.abs(b).max())
