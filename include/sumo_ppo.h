@@ -168,6 +168,11 @@ int ppo_grad(const float* params, const float* obs, int obs_stride, int ob_dim, 
              const int32_t* idx, int n, double inv_count, float cliprange, float ent_coef, float vf_coef, float* grads,
              double* stats, float* log_ratio_out, void* workspace, void* stream);
 
+/* The statistics PPOModel.train returns (model.py:138,205-213) from the sums ppo_grad accumulated: out5 = {policy loss, value loss,
+ * entropy, approxkl, clipfrac}; entropy = sum(logstd + 0.5 log(2 pi e)) of the policy the loss was evaluated with
+ * (baselines distributions.py:246-247).  logstd float32 [ac_dim] (inside the flat parameter vector), stats double[PPO_NSTATS]. */
+int ppo_loss_stats(const double* stats, const float* logstd, int ac_dim, double* out5, void* stream);
+
 /* params -= Adam(clip_by_global_norm(grads, max_grad_norm)); m, v float32 [P]; step t >= 1 (TF1 bias correction).
  * max_grad_norm <= 0 disables clipping.  stats[7] receives the global gradient norm. */
 int ppo_clip_adam(float* params, const float* grads, float* m, float* v, int P, int t, double lr, double beta1,

@@ -1358,6 +1358,23 @@ __global__ void __launch_bounds__(1024) ppo_clip_adam_kernel(float* params, cons
     params[k] -= lr_t * mk / (sqrtf(vk) + eps);                            // TF1: epsilon outside the bias correction
   }
 }
+// The five loss statistics a minibatch step reports (model.py:138 loss_names) from the accumulated sums + the entropy of the
+// diagonal Gaussian the loss was evaluated with (distributions.py:246-247: sum(logstd + 0.5 log(2 pi e)), float64 like the
+// host code it replaces): one launch instead of ten elementwise ones inside the step graph.
+__global__ void ppo_loss_stats_kernel(const double* stats, const float* logstd, int A, double* out5) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double ent = 0.0;
+  for (int i = 0; i < A; i++) ent += (double)logstd[i] + 0.5 * 2.8378770664093453;   // log(2 pi e)
+  const double cnt = stats[6];
+  out5[0] = stats[0] / cnt; out5[1] = stats[1] / cnt; out5[2] = ent; out5[3] = stats[3] / cnt; out5[4] = stats[4] / cnt;
+}
+extern "C" int ppo_loss_stats(const double* stats, const float* logstd, int ac_dim, double* out5, void* stream) {
+  if (!stats || !logstd || !out5 || ac_dim < 1) FAIL(-1, "bad arguments");
+  hipLaunchKernelGGL(ppo_loss_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, logstd, ac_dim, out5);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int ppo_clip_adam(float* params, const float* grads, float* m, float* v, int P, int t, double lr, double beta1, double beta2,
                              double eps, double max_grad_norm, double* stats, void* stream) {
   if (!params || !grads || !m || !v || P <= 0 || t < 1) FAIL(-1, "bad arguments");

@@ -158,10 +158,7 @@ class PPOModel(object):
                     cst = t.cuda.current_stream(self.device).cuda_stream
                     self._launch_loss_grad(obs, returns, actions, values, neglogpacs, weights, ent["idx"], n, cliprange, ent["adv"],
                                            ent["log_ratio"], cst)
-                    logstd = self.params[self.P - 1 - policies.HIDDEN - A:self.P - 1 - policies.HIDDEN]
-                    entropy_t = (logstd.double() + 0.5 * np.log(2.0 * np.pi * np.e)).sum()
-                    sst = self.stats
-                    ent["out"] = t.stack([sst[0] / sst[6], sst[1] / sst[6], entropy_t, sst[3] / sst[6], sst[4] / sst[6]])
+                    ent["out"] = self._loss_stats(cst)
                 ent["graph"] = graph
                 g = self._graphs[key] = ent
             except Exception as e:                     # capture unsupported here: stay on the eager path for good
@@ -231,21 +228,26 @@ class PPOModel(object):
             self.stats.copy_(self.grads[self.P:self.P + ppo_capi.NSTATS].to(t.float64))
         return self._finish_step(lr, sync, log_ratio, st)
 
+    def _loss_stats(self, st):
+        """[policy loss, value loss, entropy, approxkl, clipfrac] of the step whose sums sit in ``self.stats`` (one launch)."""
+        t = self._t
+        A = self.spec.ac_dim
+        out5 = t.empty(5, dtype=t.float64, device=self.device)
+        off = self.P - 1 - policies.HIDDEN - A                       # pi/logstd inside the flat parameter vector (checkpoint order)
+        ppo_capi.chk(ppo_capi.lib().ppo_loss_stats(self.stats.data_ptr(), self.params.data_ptr() + 4 * off, A, out5.data_ptr(), st))
+        return out5
+
     def _finish_step(self, lr, sync, log_ratio, st):
         t = self._t
         A = self.spec.ac_dim
-        # entropy of the distribution the loss was evaluated with (before the parameter update), model.py:69
-        logstd = self.params[self.P - 1 - policies.HIDDEN - A:self.P - 1 - policies.HIDDEN]
-        entropy_t = (logstd.double() + 0.5 * np.log(2.0 * np.pi * np.e)).sum()
+        # loss means + entropy of the distribution the loss was evaluated with (before the parameter update), model.py:69
+        out5 = self._loss_stats(st)
         self.t += 1
         ppo_capi.chk(ppo_capi.lib().ppo_clip_adam(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.P,
                                                    self.t, float(lr), 0.9, 0.999, 1e-5,
                                                    float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0,
                                                    self.stats.data_ptr(), st))
         if not sync:
-            st = self.stats
-            return t.stack([st[0] / st[6], st[1] / st[6], entropy_t, st[3] / st[6], st[4] / st[6]])
-        s = self.stats.cpu().numpy()
-        cnt = s[6]
-        entropy = float(entropy_t.item())
-        return [s[0] / cnt, s[1] / cnt, entropy, s[3] / cnt, s[4] / cnt, log_ratio, s[7]]
+            return out5
+        o = out5.cpu().numpy()
+        return [o[0], o[1], o[2], o[3], o[4], log_ratio, float(self.stats[7].item())]
