@@ -152,7 +152,8 @@ int ppo_vtrace(const float* rewards, const float* values, const float* neglogp, 
                float* ratio, void* stream);
 
 /* minibatch rows are data rows idx[0..n) (idx may be NULL = identity).  moments double[3] = {sum adv, sum adv^2, n}
- * with adv = returns - values. */
+ * with adv = returns - values.  Deterministic (fixed summation order).  ppo_adv_moments keeps its per-block partial sums in
+ * library-owned device memory: at most one call in flight per device and process (n <= 1 048 576). */
 int ppo_adv_moments(const float* returns, const float* values, const int32_t* idx, int n, double* moments, void* stream);
 int ppo_adv_normalize(const float* returns, const float* values, const int32_t* idx, int n, const double* moments,
                       float* adv_out, void* stream);

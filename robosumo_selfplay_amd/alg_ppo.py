@@ -245,7 +245,7 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         b_obs, b_ret, b_act, b_val, b_nlp, weights = ub["obs"], ub["returns"], ub["actions"], ub["values"], ub["neglogpacs"], ub["weights"]
         history["useful_ratio"].append(ub["useful_ratio"])
         b_obs = b_obs.contiguous()
-        epinfobuf.extend(epinfos)
+        epinfobuf.extend(epinfos[-epinfobuf.maxlen:])                    # the deque keeps the last 100 anyway (alg_ppo.py:160,347)
         # ---- minibatch SGD (alg_ppo.py:355-398)
         nsamp = b_obs.shape[0]
         mblossvals, early_stop, stop_info = [], False, None

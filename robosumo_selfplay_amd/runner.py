@@ -31,6 +31,39 @@ def anneal_alpha(update, anneal_bound):
     return 0.0
 
 
+class EpInfoList(object):
+    """The rollout's episode records of agent 0 (monitor.py:63-78: ``{'r', 'l', 't'}`` per finished episode, in (step, env) order) as
+    a read-only sequence that builds its dicts on demand: a 4096-env rollout ends ~10 000 episodes, the driver looks at the last
+    100 (``epinfobuf = deque(maxlen=100)``, alg_ppo.py:160), and 10 000 Python dicts per update cost 8 ms of a 270 ms iteration.
+    Behaves like the reference's list for ``len`` / iteration / indexing / slicing / ``deque.extend`` / ``==``."""
+
+    def __init__(self, r, l):
+        self._r = np.round(np.asarray(r, np.float64), 6)
+        self._l = np.asarray(l, np.int64)
+
+    def __len__(self):
+        return int(self._r.shape[0])
+
+    def _make(self, i):
+        return {"r": float(self._r[i]), "l": int(self._l[i]), "t": 0.0}
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return EpInfoList(self._r[i], self._l[i])
+        return self._make(range(len(self))[i])
+
+    def __iter__(self):
+        return (self._make(i) for i in range(len(self)))
+
+    def __eq__(self, other):
+        if isinstance(other, EpInfoList):
+            return np.array_equal(self._r, other._r) and np.array_equal(self._l, other._l)
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return "EpInfoList(%d episodes)" % len(self)
+
+
 class _nullctx(object):
     def __enter__(self):
         return None
@@ -354,7 +387,7 @@ class Runner(AbstractEnvRunner):
         # episode infos of agent 0 (monitor.py:63-78), harvested with one host sync per rollout
         d = B["ep_done"].cpu().numpy().astype(bool)
         rr, ll = B["ep_r"].cpu().numpy(), B["ep_l"].cpu().numpy()
-        epinfos = [{"r": round(float(rr[s, e]), 6), "l": int(ll[s, e]), "t": 0.0} for s, e in zip(*np.nonzero(d))]
+        epinfos = EpInfoList(rr[d], ll[d])          # (step, env) order of np.nonzero, dicts built on demand
         return (sf01(B["obs"]), sf01(returns), sf01(B["done"].bool()), sf01(B["act"]), sf01(B["val"]), sf01(B["nlp"]), sf01(B["rew"]),
                 sf01(B["onlp"]), sf01(B["obs"][1]), sf01(B["act"][1]), states0, epinfos, sf0(opr), sf0(oer), sf0(ratio))
 

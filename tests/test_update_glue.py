@@ -84,3 +84,18 @@ def test_selection_probs_match_oracle():
 def test_minibatch_slices_cover_ragged_batch():
     sl = po.minibatch_slices(100, 32)
     assert sl == [(0, 32), (32, 64), (64, 96), (96, 100)]
+
+
+def test_epinfo_list_behaves_like_the_reference_list():
+    """Runner's episode records (monitor.py:63-78 dicts) as a lazy sequence: len / index / slice / iteration / deque.extend / ==."""
+    from collections import deque
+    from robosumo_selfplay_amd.runner import EpInfoList
+    r = np.array([1.23456789, -2000.5, 3.0]); l = np.array([10, 501, 7])
+    ep = EpInfoList(r, l)
+    want = [{"r": round(float(a), 6), "l": int(b), "t": 0.0} for a, b in zip(r, l)]
+    assert len(ep) == 3 and list(ep) == want and ep[1] == want[1] and ep[-1] == want[-1] and ep == want
+    assert list(ep[-2:]) == want[-2:] and ep[-100:] == ep and len(EpInfoList(r[:0], l[:0])) == 0
+    d = deque(maxlen=2); d.extend(ep[-d.maxlen:])
+    assert list(d) == want[-2:]
+    with pytest.raises(IndexError):
+        ep[3]
