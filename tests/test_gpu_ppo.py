@@ -544,3 +544,28 @@ def test_learn_with_opponent_pool_matches_glue_oracle(tmp_path):
         assert np.array_equal(got[k].cpu().numpy(), want[k]), k
     assert abs(h["useful_ratio"][-1] - want["useful_ratio"]) < 1e-12
     env.close()
+
+
+@pytest.mark.parametrize("N,T,chunk", [(1, 3, 0), (2, 1, 0), (5, 7, 3), (40, 12, 5)])
+def test_rollout_kernel_edge_shapes_and_chunks(N, T, chunk):
+    """Fused rollout launch on tiny batches (fewer envs than wave slots, one env, one step) and split into several launches per
+    rollout (``rollout_chunk``: steps s0 > 0, the noise and the ring of buffers reused across launches): identical to the
+    step-by-step path."""
+    def run(fused):
+        env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=N, seed=3)
+        learner, opp = _model(121, 8, seed=5, trainable=False), _model(121, 8, seed=6, trainable=False)
+        learner.act_model.seed(1); opp.act_model.seed(2)
+        r = Runner(env=env, models=[learner, opp], nsteps=T, nagent=2, gamma=0.995, lam=0.95, rho_bar=1.0, c_bar=1.0)
+        r.fused_rollout, r.rollout_chunk = fused, chunk
+        out = [r.run(1), r.run(2)]
+        torch.cuda.synchronize()
+        st, aborts = env.engine.get_state(), env.stats()["rollout_aborts"]
+        env.close()
+        return out, st, aborts
+    (fo, fs, fa), (so, ss, _) = run(True), run(False)
+    assert fa == 0
+    for f, s_ in zip(fo, so):
+        for x, y in zip(f, s_):
+            assert torch.equal(x, y) if torch.is_tensor(x) else x == y
+    for x, y in zip(fs, ss):
+        assert np.array_equal(x, y)
