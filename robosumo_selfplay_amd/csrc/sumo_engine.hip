@@ -2454,6 +2454,7 @@ struct sumo_engine {
   int *d_cost = nullptr, *d_cost_sorted = nullptr, *d_iota = nullptr, *d_perm = nullptr;   // d_cost / d_perm: two buffers of N each
   unsigned long long* d_trace = nullptr;   // sumo_debug_trace
   void* d_launch = nullptr;                // sumo_rollout_steps: the launch's argument block (RolloutLaunch)
+  int num_cus = 0;                         // cached device property (sumo_rollout_steps sizes its persistent grid with it)
   int* d_rsched = nullptr;                 // sumo_rollout_steps: ticket counter, abort flag, per-env progress [2 + N]
   long long sched_t = 0;                                                                     // step launches so far (in-kernel ranking)
   void* d_sort_tmp = nullptr;
@@ -3118,9 +3119,12 @@ extern "C" int sumo_rollout_steps(sumo_handle_t E, const sumo_rollout* ro, float
     int slots = (int)((size_t)160 * 1024 / (size_t)E->L.total_bytes);
     if (slots > 4 * SUMO_WPE) slots = 4 * SUMO_WPE;
     if (slots < 1) slots = 1;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, E->device));
-    long long nw = (long long)slots * prop.multiProcessorCount;
+    if (E->num_cus <= 0) {
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, E->device));
+      E->num_cus = prop.multiProcessorCount;
+    }
+    long long nw = (long long)slots * E->num_cus;
     if (nw > (long long)E->N) nw = E->N;   // more waves than envs would only wait on each other's steps
     dim3 g_((unsigned)nw), b_(WAVE);
     size_t lds_ = (size_t)E->L.total_bytes;
