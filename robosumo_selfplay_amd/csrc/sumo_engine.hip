@@ -1763,7 +1763,7 @@ __device__ __forceinline__ void forward(C& c) {
     // The general (dense-factorisation) path costs ~1.65x a tree-path forward and the envs on it -- agents in contact with each
     // other, a few per launch -- are the stragglers every launch waits for (tools/slot_trace.py).  From its first dense
     // forward on, such a wave issues ahead of the wave it shares the SIMD with (which has slack).
-    if (c.st_dense == 0) __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);
     newton_solve<false>(c);
     c.st_dense++;
     if (c.hcross) c.st_cross++;
@@ -2351,6 +2351,7 @@ sumo_rollout_kernel(const Params* P, const RolloutLaunch* LP) {
       if (!ok) { if (c.lane == 0 && lp->a.stats) atomicAdd(lp->a.stats + 9, 1ull); break; }
       asm volatile("" ::: "memory");   // the env's record is read after the poll, through sc1 loads (hand_load): nothing to invalidate
     }
+    __builtin_amdgcn_s_setprio(0);   // a wave that raised its issue priority for a dense-solver step (forward()) starts the next ticket level
     // (e, k) wait in LDS during the phases (nothing but the context stays live across the forward-dynamics evaluations)
     if (c.lane == 0) { int* tk = (int*)(S(stash) + 4); tk[0] = e; tk[1] = k; }
     lp = launder_sptr(LP);
