@@ -309,6 +309,7 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         if save_interval and (update % save_interval == 0 or update == 1) and rank == 0:
             model.save(osp.join(checkdir, "%.5i" % update))               # alg_ppo.py:459-464
         if comm is not None:
+            sdist.assert_synced(model.params, comm)                       # MpiAdamOptimizer.check_synced (mpi_adam_optimizer.py:54-67)
             torch.distributed.barrier(comm)
     model.history = history
     model.time_elapsed = time.perf_counter() - tfirststart

@@ -24,12 +24,14 @@ def init_process_group(backend=None):
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:      # SUMO_DIST_BACKEND=gloo: rehearse N ranks on one GPU (RCCL refuses two ranks on one device)
+        backend = os.environ.get("SUMO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {}
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         kw["device_id"] = torch.device("cuda", local_rank)
+    elif torch.cuda.is_available():
+        local_rank = local_rank % torch.cuda.device_count()
     if not dist.is_initialized():
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return dist.group.WORLD

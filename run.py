@@ -53,6 +53,8 @@ def main(argv):
     if args.env_groups <= 0:
         args.env_groups = 2 if (args.network == "lstm" or os.environ.get("SUMO_FUSED_ROLLOUT", "1") == "0") else 1
     groups = args.env_groups if per % max(1, args.env_groups) == 0 else 1
+    import torch
+    local_rank = local_rank % max(1, torch.cuda.device_count())        # gloo rehearsal of N ranks on fewer GPUs
     env = make_vec_env(args.env, per, args.seed + start, device=local_rank, groups=groups)  # run.py:144: env i gets seed + i
     kw = defaults.get_default_params(args.env, args.algo)
     kw.update(extra)

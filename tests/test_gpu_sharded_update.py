@@ -246,3 +246,29 @@ def test_two_shards_match_single_process_recurrent():
     assert np.array_equal(res[0][0], res[1][0])
     assert np.allclose(res[0][0], ref_p, rtol=0, atol=3e-5), np.abs(res[0][0] - ref_p).max()
     assert np.allclose(res[0][1], ref_st, rtol=2e-3, atol=1e-5) and np.allclose(res[1][1], ref_st, rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_run_py_two_ranks_end_to_end(tmp_path):
+    """The whole distributed path through the CLI: `torch.distributed.run` starts two ranks of run.py (gloo over CUDA tensors, both on
+    cuda:0 -- RCCL refuses two ranks on one device), each rank owns a shard of the envs, rolls out in its own fused launch and takes
+    part in the per-step collectives; every rank ends with the same parameters as rank 0's checkpoints."""
+    import subprocess
+    import sys
+    import joblib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SUMO_DIST_BACKEND="gloo", OPENAI_LOGDIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(root, "run.py"), "--env", "RoboSumo-Ant-vs-Ant-v0", "--num_env", "32", "--num_timesteps", str(32 * 16 * 2),
+           "--log_path", str(tmp_path), "--nsteps=16", "--nminibatches=4", "--noptepochs=2", "--log_interval=1", "--opponent_mode=latest"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    ck = os.path.join(str(tmp_path), "RoboSumo-Ant-vs-Ant-v0-0", "checkpoints")
+    assert sorted(os.listdir(ck)) == ["00000", "00001", "00002"]
+    p1, p2 = joblib.load(os.path.join(ck, "00001")), joblib.load(os.path.join(ck, "00002"))
+    assert all(np.isfinite(a).all() for a in p2) and any(not np.array_equal(a, b) for a, b in zip(p1, p2))
+    assert "update 2/2" in res.stdout
