@@ -56,7 +56,7 @@ struct Aux {  // derived integer tables (built on the host in build_aux)
   int ndepth;              // levels 0..ndepth-1 (world = level 0)
   int ntri;                // nv*(nv+1)/2
   int o_lvl_adr, o_lvl_body, o_child_adr, o_child, o_chain_len, o_chain, o_bchain_len, o_bchain, o_body_agent,
-      o_tri_i, o_tri_j;
+      o_tri_i, o_tri_j, o_ent;
   int o_wgmat;  // double table: 9 per geom (valid for world geoms)
   int o_stat_d, n_stat_d, o_stat_i, n_stat_i;  // tables copied into LDS at kernel start (see build_aux)
   int o_wpa;                                   // double table: world geom positions [3*nworld] | axes [3*nworld]
@@ -408,7 +408,6 @@ struct Ctx {
   const LaneRec* kp;    // this lane's constant record (device memory, L1-resident); phases copy the fields they need
   const int* prp;       // this lane's packed pair records / bounds: element r*64
   const float* pbp;
-  unsigned ent[EPL];  // lower-triangle entries assembled by this lane (i << 8 | k), entry t = lane + 64*m; 0xFFFF = none
   const Params* P;
   double* sm;    // LDS base (doubles)
   int* si;       // LDS int region
@@ -1599,7 +1598,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
       int pi[C::EPL], pj[C::EPL];   // chain positions of the entry's two dofs (slot lookup, SLOT_OF)
 #pragma unroll
       for (int m = 0; m < C::EPL; m++) {
-        unsigned w = c.ent[m]; asm volatile("" : "+v"(w));
+        unsigned w = (unsigned)launder_ptr(c.P->aux.ai + c.P->aux.o_ent)[c.lane + WAVE * m];   // loaded here, in the rarely taken block
         ent[m] = w & 0xFFFFu;
         pi[m] = (w >> 16) & 0xF; pj[m] = (w >> 20) & 0xF;
       }
@@ -1746,8 +1745,7 @@ __device__ __forceinline__ void forward(C& c) {
   } else {  // unknown tree shape: pack M into the Hessian buffer and use the dense factorisation
 #pragma unroll
     for (int m = 0; m < C::EPL; m++) {
-      unsigned e = c.ent[m];
-      asm volatile("" : "+v"(e));   // keep the address arithmetic of this rarely taken block out of the kernel prologue
+      unsigned e = (unsigned)launder_ptr(c.P->aux.ai + c.P->aux.o_ent)[c.lane + WAVE * m];   // (address arithmetic stays in this rarely taken block)
       e &= 0xFFFFu;
       if (e != 0xFFFFu) { int i = e >> 8, jj = e & 0xFF; S(H)[HP(i, jj)] = SAME_TREE(i, jj) ? S(M)[MIDX(i, jj)] : 0.0; }
     }
@@ -1978,16 +1976,6 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.si = (int*)(smem + P->L.i_base);
   c.sb = (unsigned char*)(smem + P->L.i_base);
   c.lane = threadIdx.x;
-#pragma unroll
-  for (int m = 0; m < C::EPL; m++) {
-    int t = c.lane + WAVE * m;
-    unsigned w = 0xFFFFu;
-    if (t < P->aux.ntri) {   // bits 16..19 / 20..23: chain positions of the two dofs (slot lookup in the dense Hessian assembly)
-      const int i = P->aux.ai[P->aux.o_tri_i + t], j = P->aux.ai[P->aux.o_tri_j + t];
-      w = (unsigned)((i << 8) | j) | ((unsigned)P->lanes[i].d_pos << 16) | ((unsigned)P->lanes[j].d_pos << 20);
-    }
-    c.ent[m] = w;
-  }
   c.kp = P->lanes + c.lane;
   c.prp = P->pair_rec + c.lane;
   c.pbp = P->pair_bound + c.lane;
@@ -2749,6 +2737,18 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
       K.a_dof = SUMO_I(m, actuator_dofid)[l]; K.a_gear = SUMO_F(m, actuator_gear)[l];
       K.a_lo = SUMO_F(m, actuator_ctrlrange)[2 * l]; K.a_hi = SUMO_F(m, actuator_ctrlrange)[2 * l + 1];
     }
+  }
+  // ---- lower-triangle entry words of the dense Hessian assembly, entry t = lane + 64 m: (i << 8 | j) | chain position of dof i
+  // << 16 | of dof j << 20; 0xFFFF = none.  Read where the (rare) dense path assembles H instead of living in 7 registers of
+  // every lane for the whole launch.
+  {
+    const int epl = (A.ntri + WAVE - 1) / WAVE;
+    std::vector<int> ent((size_t)epl * WAVE, 0xFFFF);
+    for (int t = 0; t < A.ntri; t++) {
+      const int i = tri_i[t], j = tri_j[t];
+      ent[t] = (int)((unsigned)((i << 8) | j) | ((unsigned)E->lanes[i].d_pos << 16) | ((unsigned)E->lanes[j].d_pos << 20));
+    }
+    A.o_ent = push_tbl(ent);
   }
   // ---- packed pair records for the broad phase: pairs with a static world geom first (the model lists them first:
   // body-pair order, world body = 0), padded to whole rounds of 64, then the pairs between moving geoms.
