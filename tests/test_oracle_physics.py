@@ -574,3 +574,115 @@ def test_centrifugal_pendulum_period(ant_model, oracle_lib, armature):
     assert len(t_cross) >= 2
     measured = t_cross[1] - t_cross[0]
     assert measured == pytest.approx(period * (1 + theta0 ** 2 / 16), rel=2e-4), (measured, period)
+
+
+def test_contact_jacobian_rows_match_independent_point_jacobians(ant_model, spider_model, oracle_lib):
+    """Constraint Jacobian of the oracle against point Jacobians built in numpy from mjcf.mass_matrix_np's body Jacobians (a
+    different formulation from the oracle's cdof-based one).  For every pyramidal contact (condim 3: rows n +- mu t1, n +- mu t2,
+    MuJoCo's pyramid [EXT]): the mean of the four rows is the normal row n' (Jp_2 - Jp_1) at the contact point; the two
+    half-differences are mu t' (Jp_2 - Jp_1) for unit tangents t1, t2 that are orthogonal to n and to each other.  Limit rows
+    precede the contact rows and carry a single -+1."""
+    checked = 0
+    for m, N, steps in ((ant_model, 48, 50), (spider_model, 24, 40)):
+        sim = oracle_lib.OracleSim(m, N)
+        sim.reset(seeds=np.arange(N) + 5)
+        rng = np.random.default_rng(4)
+        for t in range(steps):
+            sim.step(rng.standard_normal((N, 2, sim.act_stride)).astype(np.float32) * (1.0 if t < steps // 2 else 0.2), nthreads=4)
+        qs = sim.get_state()[0]
+        gbody = m.geom_bodyid
+        for e in range(N):
+            sim.forward(e, np.zeros(m.nu))
+            ncon, nefc = int(sim.array("counts", e)[0]), int(sim.array("counts", e)[1])
+            if ncon == 0:
+                continue
+            J = sim.array("efc_J", e).reshape(nefc, m.nv)
+            con = sim.array("contacts", e).reshape(ncon, 9)
+            nlim = nefc - 4 * ncon
+            assert nlim >= 0
+            for r in range(nlim):                                   # hinge-limit rows: one entry of magnitude 1
+                nz = np.nonzero(J[r])[0]
+                assert len(nz) == 1 and abs(abs(J[r, nz[0]]) - 1.0) < 1e-15
+            M, jacp, jacr = mjcf.mass_matrix_np(m, qs[e])
+            xpos, xquat, _, _ = mjcf.kinematics_np(m, qs[e])
+            xipos = np.array([xpos[b] + mjcf.quat2mat(xquat[b]) @ m.body_ipos[b] for b in range(m.nbody)])
+
+            def point_jac(b, p):                                     # 3 x nv translational Jacobian of the point p riding on body b
+                if b == 0:
+                    return np.zeros((3, m.nv))
+                return jacp[b] + np.stack([np.cross(jacr[b][:, d], p - xipos[b]) for d in range(m.nv)], axis=1)
+            for k in range(ncon):
+                p, n = con[k, 1:4], con[k, 4:7]
+                b1, b2 = int(gbody[int(con[k, 7])]), int(gbody[int(con[k, 8])])
+                Jd = point_jac(b2, p) - point_jac(b1, p)
+                rows = J[nlim + 4 * k:nlim + 4 * k + 4]
+                scale = np.abs(Jd).max() + 1e-12
+                assert abs(np.linalg.norm(n) - 1.0) < 1e-12
+                assert np.abs(rows.mean(0) - n @ Jd).max() < 1e-10 * scale            # normal part
+                assert np.abs((rows[0] + rows[1]) - (rows[2] + rows[3])).max() < 1e-10 * scale
+                tang = []
+                for a, b_ in ((0, 1), (2, 3)):
+                    jt = 0.5 * (rows[a] - rows[b_])                                     # = mu t' Jd
+                    t_mu, res, rank, _ = np.linalg.lstsq(Jd.T, jt, rcond=None)
+                    if rank < 3:
+                        continue                                                        # degenerate Jd (cannot recover t); rare
+                    assert np.abs(Jd.T @ t_mu - jt).max() < 1e-9 * scale
+                    mu = np.linalg.norm(t_mu)
+                    assert mu > 0 and abs(t_mu @ n) < 1e-8 * mu
+                    tang.append(t_mu / mu)
+                    pair = m.pair_friction.reshape(-1, 3) if m.pair_friction.ndim == 1 else m.pair_friction
+                    assert np.isclose(mu, pair[:, 0], rtol=1e-9).any()                  # a friction coefficient of the scene
+                if len(tang) == 2:
+                    assert abs(tang[0] @ tang[1]) < 1e-8
+                checked += 1
+    assert checked >= 100, checked
+
+
+def test_capsule_on_tatami_contacts_match_geometry(ant_model, oracle_lib):
+    """Narrow phase against elementary geometry computed in numpy: a leg capsule resting on the top face of the tatami box touches
+    with one or both of its end spheres -- contact normal +-z, distance = (end-sphere centre z - radius) - top, contact point at the
+    end sphere's xy, half-way between the two surfaces (MuJoCo's contact convention [EXT]); the torso sphere likewise."""
+    m = ant_model
+    sim = oracle_lib.OracleSim(m, 32)
+    sim.reset(seeds=np.arange(32) + 40)
+    z = np.zeros((32, 2, sim.act_stride), np.float32)
+    for _ in range(60):
+        sim.step(z, nthreads=4)
+    qs = sim.get_state()[0]
+    top = float(m.geom_pos[1][2] + m.geom_size[1][2])
+    assert m.geom_names[1] == "tatami" and abs(top - 0.5) < 1e-12
+    seen = 0
+    for e in range(32):
+        sim.forward(e, np.zeros(m.nu))
+        ncon = int(sim.array("counts", e)[0])
+        if not ncon:
+            continue
+        con = sim.array("contacts", e).reshape(ncon, 9)
+        xpos, xquat, _, _ = mjcf.kinematics_np(m, qs[e])
+        for k in range(ncon):
+            g1, g2 = int(con[k, 7]), int(con[k, 8])
+            if 1 not in (g1, g2) or abs(abs(con[k, 6]) - 1.0) > 1e-12:
+                continue
+            assert con[k, 6] == (-1.0 if g2 == 1 else 1.0)          # the normal points from geom 1 to geom 2
+            g2 = g1 if g2 == 1 else g2                               # the moving geom
+            b = int(m.geom_bodyid[g2])
+            R = mjcf.quat2mat(mjcf.quat_mul(xquat[b], m.geom_quat[g2]))
+            centre = xpos[b] + mjcf.quat2mat(xquat[b]) @ m.geom_pos[g2]
+            r = float(m.geom_size[g2][0])
+            if m.geom_type[g2] == mjcf.GEOM_SPHERE:
+                ends = [centre]
+            elif m.geom_type[g2] == mjcf.GEOM_CAPSULE:
+                h = float(m.geom_size[g2][1])
+                ends = [centre + R[:, 2] * h, centre - R[:, 2] * h]
+            else:
+                continue
+            p = con[k, 1:4]
+            end = min(ends, key=lambda c_: np.linalg.norm(c_[:2] - p[:2]))
+            if np.linalg.norm(end[:2] - p[:2]) > 1e-9:
+                continue                                            # an interior (edge-on) contact point of the capsule axis: not this test
+            dist = end[2] - r - top
+            assert abs(con[k, 0] - dist) < 1e-10, (con[k, 0], dist)
+            assert abs(p[2] - (top + 0.5 * dist)) < 1e-10
+            assert max(abs(p[0]), abs(p[1])) <= m.geom_size[1][0] + 1e-9    # on the top face
+            seen += 1
+    assert seen >= 40, seen
