@@ -453,7 +453,8 @@ def _rollout_pair(env_id, N, T, groups, fused, seed=3, pool=None, opp_params=Non
 
 
 @pytest.mark.parametrize("env_id,N,T,groups", [("RoboSumo-Ant-vs-Ant-v0", 96, 24, 1), ("RoboSumo-Ant-vs-Ant-v0", 64, 12, 2),
-                                               ("RoboSumo-Spider-vs-Spider-v0", 32, 8, 1)])
+                                               ("RoboSumo-Spider-vs-Spider-v0", 32, 8, 1),
+                                               ("RoboSumo-Ant-vs-Ant-v0", 4096, 16, 1)])   # BASELINE configs[1] size: 2 tickets per wave slot, envs migrate between waves and XCDs
 def test_rollout_kernel_matches_stepwise_path(env_id, N, T, groups):
     """sumo_rollout_steps (policies + env steps + buffer appends of a whole rollout in ONE launch) against the step-by-step
     launches it replaces (ppo_selfplay_forward, sumo_step, ppo_post_step per step): every returned array of Runner.run, the
