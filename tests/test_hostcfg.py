@@ -1,0 +1,59 @@
+"""Host thread budget (robosumo_selfplay_amd/hostcfg.py): the cgroup CPU quota is what the pools must be sized by, not os.cpu_count()
+(the cause of the bimodal short bench window of round 1: DESIGN.md §4, bench reproducibility)."""
+import builtins
+import io
+import os
+
+from robosumo_selfplay_amd import hostcfg
+
+
+def _fake_open(files):
+    real = builtins.open
+
+    def f(path, *a, **k):
+        if path in files:
+            if files[path] is None:
+                raise OSError(path)
+            return io.StringIO(files[path])
+        return real(path, *a, **k)
+    return f
+
+
+def test_cpu_quota_reads_cgroup_v2_and_v1(monkeypatch):
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", _fake_open({"/sys/fs/cgroup/cpu.max": "1600000 100000\n"}))
+    assert hostcfg.cpu_quota() == 16
+    monkeypatch.setattr(builtins, "open", _fake_open({"/sys/fs/cgroup/cpu.max": "max 100000\n"}))
+    assert hostcfg.cpu_quota() == 256
+    monkeypatch.setattr(builtins, "open", _fake_open({"/sys/fs/cgroup/cpu.max": None, "/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "800000\n",
+                                                       "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"}))
+    assert hostcfg.cpu_quota() == 8
+    monkeypatch.setattr(builtins, "open", _fake_open({"/sys/fs/cgroup/cpu.max": "50000 100000\n"}))
+    assert hostcfg.cpu_quota() == 1                                      # never below one
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(4)), raising=False)
+    monkeypatch.setattr(builtins, "open", _fake_open({"/sys/fs/cgroup/cpu.max": "1600000 100000\n"}))
+    assert hostcfg.cpu_quota() == 4                                      # the affinity mask caps it too
+
+
+def test_apply_caps_pools_and_respects_overrides(monkeypatch):
+    for v in hostcfg._VARS:
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.delenv("SUMO_HOST_THREADS", raising=False)
+    monkeypatch.setattr(hostcfg, "_applied", None)
+    monkeypatch.setattr(hostcfg, "cpu_quota", lambda: 16)
+    assert hostcfg.apply() == 8 and os.environ["OMP_NUM_THREADS"] == "8" and os.environ["OPENBLAS_NUM_THREADS"] == "8"
+    assert hostcfg.apply() == 8                                           # idempotent
+    monkeypatch.setattr(hostcfg, "_applied", None)
+    monkeypatch.setenv("SUMO_HOST_THREADS", "0")
+    assert hostcfg.apply() == 0                                           # opt-out
+    monkeypatch.setattr(hostcfg, "_applied", None)
+    monkeypatch.setenv("SUMO_HOST_THREADS", "3")
+    monkeypatch.setenv("OMP_NUM_THREADS", "5")                            # a user's own setting is not overridden
+    assert hostcfg.apply() == 3 and os.environ["OMP_NUM_THREADS"] == "5"
+
+
+def test_throttle_stats_parses_cpu_stat(monkeypatch):
+    monkeypatch.setattr(builtins, "open", _fake_open({"/sys/fs/cgroup/cpu.stat": "usage_usec 10\nnr_periods 5\nnr_throttled 3\nthrottled_usec 12345\n"}))
+    assert hostcfg.throttle_stats() == (3, 12345)
+    monkeypatch.setattr(builtins, "open", _fake_open({"/sys/fs/cgroup/cpu.stat": None}))
+    assert hostcfg.throttle_stats() is None
