@@ -2293,9 +2293,10 @@ __device__ __forceinline__ void rollout_post_phase(C& c, const StepArgs& a, cons
   }
 }
 
-// The launch arguments live in device memory and are re-read through a laundered pointer in every iteration: as by-value
-// kernel arguments their loads are loop-invariant, get hoisted out of the step loop and stay live across the twenty
-// forward-dynamics evaluations of every step (the kernel sits exactly at its 256-register budget).
+// The launch arguments are re-read through a laundered pointer in every iteration: accessed as ordinary by-value kernel
+// arguments their loads are loop-invariant, get hoisted out of the step loop and stay live across the twenty forward-dynamics
+// evaluations of every step (the kernel sits exactly at its 256-register budget).  The pointer addresses the kernel-argument
+// segment itself, where the runtime has placed the struct at launch (no separate copy to keep alive).
 struct RolloutLaunch { StepArgs a; RolloutArgs r; };
 
 // Scheduling: the launch is a set of persistent waves (one per wave slot of the chip) that draw TICKETS from a global counter;
@@ -2313,7 +2314,11 @@ struct RolloutLaunch { StepArgs a; RolloutArgs r; };
 
 template <int NV>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE_OF(NV), SUMO_WPE_OF(NV))))
-sumo_rollout_kernel(const Params* P, const RolloutLaunch* LP) {
+sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
+  // `launch_args` is read in place from the kernel-argument segment (second argument, 8-byte aligned right behind P) through a
+  // pointer the loop launders per ticket -- see the note above RolloutLaunch
+  (void)launch_args;
+  const RolloutLaunch* LP = (const RolloutLaunch*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(const Params*));
   Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   for (;;) {
@@ -2447,7 +2452,6 @@ struct sumo_engine {
   // longest-first scheduling of the env steps (see sumo_step)
   int *d_cost = nullptr, *d_cost_sorted = nullptr, *d_iota = nullptr, *d_perm = nullptr;   // d_cost / d_perm: two buffers of N each
   unsigned long long* d_trace = nullptr;   // sumo_debug_trace
-  void* d_launch = nullptr;                // sumo_rollout_steps: the launch's argument block (RolloutLaunch)
   int num_cus = 0;                         // cached device property (sumo_rollout_steps sizes its persistent grid with it)
   int* d_rsched = nullptr;                 // sumo_rollout_steps: ticket counter, abort flag, per-env progress [2 + N]
   long long sched_t = 0;                                                                     // step launches so far (in-kernel ranking)
@@ -2986,7 +2990,7 @@ extern "C" int sumo_destroy(sumo_handle_t E) {
   if (!E) return 0;
   (void)hipSetDevice(E->device);
   (void)hipFree(E->d_params); (void)hipFree(E->d_lanes); (void)hipFree(E->d_pair_rec); (void)hipFree(E->d_pair_bound); (void)hipFree(E->d_blob); (void)hipFree(E->d_ai); (void)hipFree(E->d_af); (void)hipFree(E->d_pic); (void)hipFree(E->d_state);
-  (void)hipFree(E->d_counters); (void)hipFree(E->d_seeds); (void)hipFree(E->d_stats); (void)hipFree(E->d_launch); (void)hipFree(E->d_rsched);
+  (void)hipFree(E->d_counters); (void)hipFree(E->d_seeds); (void)hipFree(E->d_stats); (void)hipFree(E->d_rsched);
   (void)hipFree(E->d_cost); (void)hipFree(E->d_cost_sorted); (void)hipFree(E->d_iota); (void)hipFree(E->d_perm); (void)hipFree(E->d_sort_tmp);
   delete E;
   return 0;
@@ -3114,12 +3118,9 @@ extern "C" int sumo_rollout_steps(sumo_handle_t E, const sumo_rollout* ro, float
   a.actions = actions_dev; a.obs = obs_dev; a.info = info_dev; a.done = done_dev; a.ep_r = ep_r_dev; a.ep_dr = ep_dr_dev; a.ep_l = ep_l_dev;
   rl.r = r;
   hipStream_t st_ = (hipStream_t)stream;
-  if (!E->d_launch) HIPCHK(hipMalloc(&E->d_launch, sizeof(RolloutLaunch)));
   if (!E->d_rsched) HIPCHK(hipMalloc((void**)&E->d_rsched, (size_t)(2 + E->N) * sizeof(int)));
   HIPCHK(hipMemsetAsync(E->d_rsched, 0, (size_t)(2 + E->N) * sizeof(int), st_));
   rl.r.sched = E->d_rsched;
-  // stream-ordered: the previous launch of this engine (same stream) has finished reading the block before it is overwritten
-  HIPCHK(hipMemcpyAsync(E->d_launch, &rl, sizeof rl, hipMemcpyHostToDevice, st_));
   {
     // persistent waves: as many as the chip holds at this kernel's LDS footprint (8 per CU at most: two per SIMD)
     int slots = (int)((size_t)160 * 1024 / (size_t)E->L.total_bytes);
@@ -3134,9 +3135,8 @@ extern "C" int sumo_rollout_steps(sumo_handle_t E, const sumo_rollout* ro, float
     if (nw > (long long)E->N) nw = E->N;   // more waves than envs would only wait on each other's steps
     dim3 g_((unsigned)nw), b_(WAVE);
     size_t lds_ = (size_t)E->L.total_bytes;
-    const RolloutLaunch* lp_ = (const RolloutLaunch*)E->d_launch;
     if (!for_kernel_variant(E->hm.nv, [&](auto nvc_) {
-          hipLaunchKernelGGL(sumo_rollout_kernel<decltype(nvc_)::value>, g_, b_, lds_, st_, E->d_params, lp_);
+          hipLaunchKernelGGL(sumo_rollout_kernel<decltype(nvc_)::value>, g_, b_, lds_, st_, E->d_params, rl);
         }))
       FAIL(-19, "no kernel variant for nv=%d", E->hm.nv);
   }
