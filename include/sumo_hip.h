@@ -66,7 +66,9 @@ int sumo_step(sumo_handle_t h, const float* actions_dev, float* obs_dev, double*
  *     ep_done uint8 / ep_r float64 / ep_l int32 [T][Ntot] (agent 0's episode records, monitor.py:63-78); this engine's envs are
  *     columns env_offset .. env_offset + E - 1; steps s0 .. s0 + K - 1 are written
  *   alpha: weight of the shaping reward (runner.py:130-134)
- * The env-side buffers are those of sumo_step (actions is written: it receives the sampled actions). */
+ * The env-side buffers are those of sumo_step (actions is written: it receives the sampled actions).  Launches of one engine must
+ * be ordered on one stream (the engine owns the launch's ticket / progress counters); different engines may run concurrently.
+ * After the launch obs / done hold the state after the last step as after sumo_step; info / ep_* hold the last step's values. */
 typedef struct sumo_rollout {
   const float* learner_params;
   const float* opponent_params;
