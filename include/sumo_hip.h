@@ -32,6 +32,7 @@
 #define SUMO_HIP_H
 #include <stddef.h>
 #include <stdint.h>
+#include "sumo_ppo.h"   /* ppo_lstm_net (sumo_rollout_steps_lstm) */
 
 #ifdef __cplusplus
 extern "C" {
@@ -84,6 +85,35 @@ typedef struct sumo_rollout {
 } sumo_rollout;
 int sumo_rollout_steps(sumo_handle_t h, const sumo_rollout* r, float* actions_dev, float* obs_dev, double* info_dev, uint8_t* done_dev,
                        double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream);
+
+/* The same launch for RECURRENT policies (learn(network='lstm'): baselines lstm(128), value head on the same latent;
+ * Runner's recurrent branch = reference runner.py:62-96 with the S / M feeds of models.py:163-170).  Per step and env the wave
+ * evaluates: learner(obs 0, state0) -> action 0 / neglogp / value / new state0; opponent(obs 0, zero state) -> its likelihood of
+ * action 0; opponent(obs 1, state1) -> action 1 / its neglogp / new state1; learner(obs 1, NEW state1) -> the value recorded for
+ * agent 1; learner(obs 1, zero state) -> its likelihood of action 1.  State rows are zeroed where the previous step's done flag
+ * is set before a cell runs.  Numbers equal the ppo_lstm_step launches of the step-by-step path bit for bit.
+ *   learner        HOST struct (device pointers inside): hidden 128, gate order i,f,o,u, no embedding / observation filter
+ *   opponents_dev  DEVICE array of npool structs of the same shape; tile_net_dev DEVICE int32 [Ntot / 16]: the snapshot every
+ *                  16-env tile of the WHOLE env set faces (tile of env e of this engine: (env_offset + e) / 16), NULL = snapshot 0
+ *   state0/state1  DEVICE float32 [E][256] (c | h): recurrent state of agent 0's / agent 1's acting net, rows of THIS engine's
+ *                  envs; read at step s0, left at the state after step s0 + K - 1
+ * Everything else as sumo_rollout.  Ordering contract as sumo_rollout_steps. */
+typedef struct sumo_rollout_lstm {
+  const ppo_lstm_net* learner;
+  const ppo_lstm_net* opponents_dev;
+  const int32_t* tile_net_dev;
+  int npool;
+  float *state0, *state1;
+  int T, Ntot, env_offset, s0, K;
+  double alpha;
+  const float *noise0, *noise1;
+  float *obs, *act, *rew, *val, *nlp, *onlp;
+  uint8_t *done, *ep_done;
+  double* ep_r;
+  int32_t* ep_l;
+} sumo_rollout_lstm;
+int sumo_rollout_steps_lstm(sumo_handle_t h, const sumo_rollout_lstm* r, float* actions_dev, float* obs_dev, double* info_dev,
+                            uint8_t* done_dev, double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream);
 int sumo_get_state(sumo_handle_t h, double* qpos, double* qvel, double* warm, int32_t* counters /* [E][2] */);
 int sumo_set_state(sumo_handle_t h, const double* qpos, const double* qvel, const double* warm,
                    const int32_t* counters);

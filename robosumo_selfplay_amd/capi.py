@@ -30,6 +30,16 @@ class Rollout(C.Structure):
                 ("done", C.c_void_p), ("ep_done", C.c_void_p), ("ep_r", C.c_void_p), ("ep_l", C.c_void_p)]
 
 
+class RolloutLstm(C.Structure):
+    """``sumo_rollout_lstm`` of include/sumo_hip.h (``learner``: pointer to a host ``ppo_capi.LstmNet``; the rest device pointers)."""
+    _fields_ = [("learner", C.c_void_p), ("opponents_dev", C.c_void_p), ("tile_net_dev", C.c_void_p), ("npool", C.c_int),
+                ("state0", C.c_void_p), ("state1", C.c_void_p),
+                ("T", C.c_int), ("Ntot", C.c_int), ("env_offset", C.c_int), ("s0", C.c_int), ("K", C.c_int),
+                ("alpha", C.c_double), ("noise0", C.c_void_p), ("noise1", C.c_void_p),
+                ("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("val", C.c_void_p), ("nlp", C.c_void_p), ("onlp", C.c_void_p),
+                ("done", C.c_void_p), ("ep_done", C.c_void_p), ("ep_r", C.c_void_p), ("ep_l", C.c_void_p)]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -46,6 +56,7 @@ def lib():
         L.sumo_reset.argtypes = [vp, vp, vp, vp, vp]
         L.sumo_step.argtypes = [vp] * 9
         L.sumo_rollout_steps.argtypes = [vp, C.POINTER(Rollout)] + [vp] * 8
+        L.sumo_rollout_steps_lstm.argtypes = [vp, C.POINTER(RolloutLstm)] + [vp] * 8
         L.sumo_get_state.argtypes = [vp] * 5
         L.sumo_set_state.argtypes = [vp] * 5
         L.sumo_debug_forward.argtypes = [vp] * 4
@@ -54,7 +65,7 @@ def lib():
         L.sumo_debug_trace.argtypes = [vp, vp]
         L.sumo_debug_trace.restype = i32
         L.sumo_profile.restype = i32
-        for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps", "sumo_get_state",
+        for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps", "sumo_rollout_steps_lstm", "sumo_get_state",
                   "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
             getattr(L, n).restype = i32
         _LIB = L
@@ -62,7 +73,7 @@ def lib():
 
 
 EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps",
-           "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace")
+           "sumo_rollout_steps_lstm", "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace")
 
 
 def _np(a):
@@ -113,6 +124,10 @@ class Engine:
     def rollout_steps(self, ro, actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream=None):
         """K fused self-play rollout steps (``sumo_rollout_steps``); ``ro`` is a filled :class:`Rollout`."""
         _chk(lib().sumo_rollout_steps(self.h, C.byref(ro), actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream))
+
+    def rollout_steps_lstm(self, ro, actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream=None):
+        """The same for recurrent policies (``sumo_rollout_steps_lstm``); ``ro`` is a filled :class:`RolloutLstm`."""
+        _chk(lib().sumo_rollout_steps_lstm(self.h, C.byref(ro), actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream))
 
     def get_state(self):
         qpos = np.zeros((self.N, self.nq))

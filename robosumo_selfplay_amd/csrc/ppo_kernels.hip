@@ -279,7 +279,6 @@ extern "C" int ppo_selfplay_forward(const float* learner_params, const float* op
 // quarter of the units).  LDS per workgroup: x [16][XS] | emb [16][HS] | h_prev [16][HP] | h_new [16][HP]
 // ---------------------------------------------------------------------------------------------------------
 #define LSTM_MAXH 128
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 struct LstmArgs {
   ppo_lstm_net net;
@@ -407,8 +406,8 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
       const int row = r0 + 4 * kq + r;
       float cp = 0.0f;
       if (row < a.n) { cp = a.c[(size_t)row * a.state_stride + j]; if (a.mask) cp *= 1.0f - a.mask[row]; }
-      const float ig = sigmoidf_(zi[r] + bi), fg = sigmoidf_(zf[r] + bf), og = sigmoidf_(zo[r] + bo), ug = tanhf(zu[r] + bu);
-      const float cn = fg * cp + ig * ug, tcn = tanhf(cn), hn = og * tcn;
+      const LstmCell cell = lstm_cell(zi[r], zf[r], zo[r], zu[r], bi, bf, bo, bu, cp);   // shared with the fused rollout kernel (ppo_tile.h)
+      const float ig = cell.ig, fg = cell.fg, og = cell.og, ug = cell.ug, cn = cell.cn, tcn = cell.tcn, hn = cell.hn;
       if (row < a.n) {
         a.c[(size_t)row * a.state_stride + j] = cn; a.h[(size_t)row * a.state_stride + j] = hn;
         if (a.sv_gates) {
@@ -440,15 +439,14 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
       const bool ok = col && row < a.n;
       const float m = m4[r] + hb;
       float act = m;
+      const bool sample = !a.given && a.noise;
+      if (ok && a.given) act = a.given[(size_t)row * A + i];
+      const float nlp = gauss_row(m, std, sum_logstd, ok, sample, (ok && sample) ? a.noise[(size_t)row * A + i] : 0.0f, act, A);
       if (ok) {
-        if (a.given) act = a.given[(size_t)row * A + i];
-        else if (a.noise) act = m + std * a.noise[(size_t)row * A + i];
         if (a.action) a.action[(size_t)row * A + i] = act;
         if (a.mean) a.mean[(size_t)row * A + i] = m;
       }
-      const float zz = ok ? (act - m) / std : 0.0f;
-      const float ss = row16_sum(zz * zz);
-      if (a.neglogp && i == 0 && row < a.n) a.neglogp[row] = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
+      if (a.neglogp && i == 0 && row < a.n) a.neglogp[row] = nlp;
     }
   }
   if (wid == 1 && N.vf_w && a.value) {

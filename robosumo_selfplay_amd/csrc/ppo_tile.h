@@ -178,4 +178,99 @@ __device__ __forceinline__ float reward_mix(double alpha, double shaping, double
   return (float)(alpha * shaping + (1 - alpha) * main_r);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// recurrent nets (baselines lstm(nlstm), a2c/utils.py:82-103): pieces shared by ppo_lstm_step_kernel (16-row MFMA tiles,
+// ppo_kernels.hip) and the fused rollout kernel (an env's few rows on the vector ALU, sumo_engine.hip)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pt_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct LstmCell { float ig, fg, og, ug, cn, tcn, hn; };
+// gate pre-activations (bias not yet added; bf carries the forget-bias offset) and the previous cell -> gates, new cell, latent
+__device__ __forceinline__ LstmCell lstm_cell(float zi, float zf, float zo, float zu, float bi, float bf, float bo, float bu, float cp) {
+  LstmCell o;
+  o.ig = pt_sigmoid(zi + bi); o.fg = pt_sigmoid(zf + bf); o.og = pt_sigmoid(zo + bo); o.ug = tanhf(zu + bu);
+  o.cn = __builtin_fmaf(o.fg, cp, o.ig * o.ug);   // one explicit contraction, so every caller rounds alike
+  o.tcn = tanhf(o.cn); o.hn = o.og * o.tcn;
+  return o;
+}
+
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));   // two floats at dword alignment (rows of a snapshot pool start at odd offsets)
+
+// Gate pre-activations of R rows on the vector ALU, equal bit for bit to the MFMA tiles of ppo_lstm_step_kernel: an f32 MFMA
+// adds its four k-products to C as sequential FMAs in ascending k, so a lane that owns a column and
+// runs fmaf over the input block (k = 0 .. D-1) and then the recurrent block (k = 0 .. NH-1) reproduces that column of the
+// tile.  One env has 2-3 rows per net: on a 16-row tile 13 of 16 rows would be idle and every B operand a 256-byte load; here a
+// lane owns the units 2 lane, 2 lane + 1 -- all four gates of them, columns g NH + 2 lane + {0, 1} -- and a k-step costs four
+// 512-byte loads for the whole wave.  xr[r] / hr[r]: LDS rows (16-byte aligned; x rows zero-padded to a multiple of four).
+template <int NH, int R>
+__device__ __forceinline__ void lstm_gates_valu(const float* wx, const float* wh, int D, const float* const (&xr)[R], const float* const (&hr)[R],
+                                                int lane, float (&z)[4][2][R]) {
+  static_assert(NH == 128, "two units per lane");
+  const int nx = (D + 3) >> 2, nch = nx + NH / 4;
+  const int col = 2 * lane;
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int r = 0; r < R; r++) { z[g][0][r] = 0.0f; z[g][1][r] = 0.0f; }
+  auto fetch = [&](int ch, f32x2u (&w)[4][4]) {
+    const bool in_x = ch < nx;
+    const float* base = in_x ? wx : wh;
+    const int k0 = 4 * (in_x ? ch : ch - nx), kmax = in_x ? D : NH;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      int k = k0 + kk;
+      if (k >= kmax) k = kmax - 1;   // the x rows are zero there: fma(0, w, z) == z for any finite weight
+      const float* wrow = base + (size_t)k * 4 * NH + col;
+#pragma unroll
+      for (int g = 0; g < 4; g++) w[kk][g] = *(const f32x2u*)(wrow + g * NH);
+    }
+  };
+  auto consume = [&](int ch, const f32x2u (&w)[4][4]) {
+    const bool in_x = ch < nx;
+    const int k0 = 4 * (in_x ? ch : ch - nx);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const float4 xv = *(const float4*)((in_x ? xr[r] : hr[r]) + k0);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          z[g][0][r] = __builtin_fmaf(xs[kk], w[kk][g].x, z[g][0][r]);
+          z[g][1][r] = __builtin_fmaf(xs[kk], w[kk][g].y, z[g][1][r]);
+        }
+    }
+  };
+  f32x2u w0[4][4], w1[4][4];   // the loads of chunk c + 1 are in flight during the products of chunk c
+  fetch(0, w0);
+  for (int ch = 0; ch < nch; ch += 2) {
+    if (ch + 1 < nch) fetch(ch + 1, w1);
+    consume(ch, w0);
+    if (ch + 2 < nch) fetch(ch + 2, w0);
+    if (ch + 1 < nch) consume(ch + 1, w1);
+  }
+}
+
+// Heads on R latent rows in LDS (hn [R][NH]): lane i < A accumulates column i of the Gaussian mean, lane 16 the value, over the
+// units in ascending order (the k order of the head tiles of ppo_lstm_step_kernel); biases are added by the caller.
+template <int NH, int R>
+__device__ __forceinline__ void lstm_heads_valu(const float* head_w, const float* vf_w, int A, const float* hn, int lane, float (&acc)[R]) {
+  const bool pi = lane < A, vf = lane == 16;
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = 0.0f;
+  for (int j0 = 0; j0 < NH; j0 += 16) {
+    float w[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) w[u] = pi ? head_w[(j0 + u) * A + lane] : (vf ? vf_w[j0 + u] : 0.0f);
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 hv = *(const float4*)(hn + r * NH + j0 + 4 * q);
+        acc[r] = __builtin_fmaf(hv.x, w[4 * q], acc[r]); acc[r] = __builtin_fmaf(hv.y, w[4 * q + 1], acc[r]);
+        acc[r] = __builtin_fmaf(hv.z, w[4 * q + 2], acc[r]); acc[r] = __builtin_fmaf(hv.w, w[4 * q + 3], acc[r]);
+      }
+  }
+}
+
 #endif

@@ -26,6 +26,7 @@
 
 #include "../../include/sumo_hip.h"
 #include "../../include/sumo_model.h"
+#include "../../include/sumo_ppo.h"   /* ppo_lstm_net: the recurrent nets of the fused rollout */
 #include "ppo_tile.h"   /* MLP(64,64) trunk / Gaussian head on one MFMA tile: the policy phase of the fused rollout kernel */
 
 #define WAVE 64
@@ -2223,6 +2224,12 @@ struct RolloutArgs {
   int* sched;                        // ticket counter | abort flag | finished steps per env [N] (zeroed by the host per launch)
   unsigned long long* prof;          // development (sumo_debug_trace): [N][4] wave start, end, ticks in the policy phases, ticks in the env steps (100 MHz)
   ParamLayout L;
+  // recurrent policies (sumo_rollout_steps_lstm): the learner's net, the opponent snapshots (device array) with the snapshot of
+  // every 16-env tile of the whole env set (NULL: snapshot 0), and the acting nets' states [N][2 hidden] (c | h) per agent
+  ppo_lstm_net lnet;
+  const ppo_lstm_net* onets;
+  const int32_t* tile_net;
+  float *st0, *st1;
 };
 
 template <class C>
@@ -2277,6 +2284,127 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const StepArgs& a, co
   wave_sync();   // the action buffer is read back by the env step (other lanes), the scratch region becomes the mass matrix again
 }
 
+// The same phase for recurrent policies (baselines lstm(128) with shared value head; Runner._step_group's recurrent branch,
+// reference runner.py:62-96 with the S / M feeds of models.py:163-170).  Five evaluations per step, two passes over weights:
+//   opponent net: row A = (obs 1, agent 1's state)  -> action 1, its neglogp (opponent_neglogp), agent 1's NEW state
+//                 row B = (obs 0, zero state)        -> the opponent's likelihood of action 0 (runner.py:85 feeds no state)
+//   learner net:  row C = (obs 0, agent 0's state)  -> action 0, neglogp, value, agent 0's new state
+//                 row D = (obs 1, agent 1's new state, masked again) -> the value recorded for agent 1 (runner.py:93)
+//                 row E = (obs 1, zero state)        -> the learner's likelihood of action 1
+// Gate pre-activations run on the vector ALU in the MFMA tiles' accumulation order (lstm_gates_valu), cell update and heads
+// through the functions ppo_lstm_step_kernel uses: every number equals the launch-per-evaluation path bit for bit.
+// LDS (floats, from lds_off): x [2][XS] | zero row [NH] | previous latents [3][NH] | new latents [3][NH].
+template <int NH, class C>
+__device__ __forceinline__ void rollout_policy_phase_lstm(C& c, const StepArgs& a, const RolloutArgs& r, int e, int s) {
+  const int lane = c.lane;
+  const ppo_lstm_net& NL = r.lnet;
+  const int D = NL.ob_dim, A = NL.ac_dim, XS = r.XS;
+  float* xo = (float*)(c.sm + r.lds_off);
+  float* hz = xo + 2 * XS;
+  float* hp = hz + NH;
+  float* hn = hp + 3 * NH;
+  const size_t col = (size_t)r.env_offset + e;
+  const size_t slot0 = ((size_t)0 * r.T + s) * r.Ntot + col, slot1 = ((size_t)1 * r.T + s) * r.Ntot + col;
+  const float* ob = a.obs + (size_t)e * 2 * a.obs_stride;
+  for (int k = lane; k < XS; k += WAVE) {
+    float o0 = 0.0f, o1 = 0.0f;
+    if (k < D) {
+      o0 = hand_load<true>(ob + k); o1 = hand_load<true>(ob + a.obs_stride + k);
+      r.obs[slot0 * D + k] = o0; r.obs[slot1 * D + k] = o1;
+    }
+    xo[k] = o0; xo[XS + k] = o1;
+  }
+  const unsigned dn = hand_load<true>((const uint16_t*)(a.done + 2 * e));   // done flags of the previous step = the masks M
+  if (lane < 2) r.done[lane == 0 ? slot0 : slot1] = (uint8_t)(dn >> (8 * lane));
+  const float keep0 = 1.0f - (float)(dn & 0xff), keep1 = 1.0f - (float)((dn >> 8) & 0xff);
+  // the acting nets' states: lane owns the units 2 lane, 2 lane + 1
+  float* s0p = r.st0 + (size_t)e * 2 * NH;
+  float* s1p = r.st1 + (size_t)e * 2 * NH;
+  const int j0 = 2 * lane;
+  float c0[2], c1[2], cD[2];
+  {
+    union { unsigned long long u; float f[2]; } q;
+    q.u = hand_load<true>((const unsigned long long*)(s0p + j0)); c0[0] = q.f[0] * keep0; c0[1] = q.f[1] * keep0;
+    q.u = hand_load<true>((const unsigned long long*)(s1p + j0)); c1[0] = q.f[0] * keep1; c1[1] = q.f[1] * keep1;
+    q.u = hand_load<true>((const unsigned long long*)(s0p + NH + j0)); hp[NH + j0] = q.f[0] * keep0; hp[NH + j0 + 1] = q.f[1] * keep0;
+    q.u = hand_load<true>((const unsigned long long*)(s1p + NH + j0)); hp[j0] = q.f[0] * keep1; hp[j0 + 1] = q.f[1] * keep1;
+    hz[j0] = 0.0f; hz[j0 + 1] = 0.0f;
+  }
+  wave_sync();
+  const ppo_lstm_net* NOp = r.onets + (r.tile_net ? r.tile_net[col >> 4] : 0);
+  const bool ok = lane < A;
+  const size_t nz = ((size_t)s * a.N + e) * A + lane;
+  float act0 = 0.0f, act1 = 0.0f, onlp1, mOB, stdO, sumO;
+  {  // ---- opponent net: rows A, B
+    const float *owx = NOp->wx, *owh = NOp->wh, *ob_ = NOp->b;
+    const float fb = NOp->forget_bias;
+    float z[4][2][2];
+    const float* const xr[2] = {xo + XS, xo};
+    const float* const hr[2] = {hp, hz};
+    lstm_gates_valu<NH, 2>(owx, owh, D, xr, hr, lane, z);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int j = j0 + u;
+      const float bi = ob_[j], bf = ob_[NH + j] + fb, bo = ob_[2 * NH + j], bu = ob_[3 * NH + j];   // gate order i, f, o, u
+      const LstmCell ca = lstm_cell(z[0][u][0], z[1][u][0], z[2][u][0], z[3][u][0], bi, bf, bo, bu, c1[u]);
+      const LstmCell cb = lstm_cell(z[0][u][1], z[1][u][1], z[2][u][1], z[3][u][1], bi, bf, bo, bu, hz[j]);
+      hand_store<true>(s1p + j, ca.cn); hand_store<true>(s1p + NH + j, ca.hn);      // agent 1's state after the opponent's step
+      hn[j] = ca.hn; hn[NH + j] = cb.hn;
+      cD[u] = ca.cn * keep1; hp[2 * NH + j] = ca.hn * keep1;                         // row D: masked once more by the same flag
+    }
+    wave_sync();
+    float m[2];
+    lstm_heads_valu<NH, 2>(NOp->head_w, NOp->vf_w, A, hn, lane, m);
+    const float hb = ok ? NOp->head_b[lane] : 0.0f, ls = ok ? NOp->logstd[lane] : 0.0f;
+    stdO = expf(ls); sumO = row16_sum(ls);
+    mOB = m[1] + hb;
+    const float n1 = ok ? r.noise1[nz] : 0.0f;
+    onlp1 = gauss_row(m[0] + hb, stdO, sumO, ok, true, n1, act1, A);     // the opponent samples for agent 1
+    wave_sync();   // the latent rows are rewritten by the learner's pass
+  }
+  float nlp0, nlp1, onlp0, v0, v1;
+  {  // ---- learner net: rows C, D, E
+    const float fb = NL.forget_bias;
+    float z[4][2][3];
+    const float* const xr[3] = {xo, xo + XS, xo + XS};
+    const float* const hr[3] = {hp + NH, hp + 2 * NH, hz};
+    lstm_gates_valu<NH, 3>(NL.wx, NL.wh, D, xr, hr, lane, z);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int j = j0 + u;
+      const float bi = NL.b[j], bf = NL.b[NH + j] + fb, bo = NL.b[2 * NH + j], bu = NL.b[3 * NH + j];
+      const LstmCell cc = lstm_cell(z[0][u][0], z[1][u][0], z[2][u][0], z[3][u][0], bi, bf, bo, bu, c0[u]);
+      const LstmCell cd = lstm_cell(z[0][u][1], z[1][u][1], z[2][u][1], z[3][u][1], bi, bf, bo, bu, cD[u]);
+      const LstmCell ce = lstm_cell(z[0][u][2], z[1][u][2], z[2][u][2], z[3][u][2], bi, bf, bo, bu, hz[j]);
+      hand_store<true>(s0p + j, cc.cn); hand_store<true>(s0p + NH + j, cc.hn);      // agent 0's state after the learner's step
+      hn[j] = cc.hn; hn[NH + j] = cd.hn; hn[2 * NH + j] = ce.hn;
+    }
+    wave_sync();
+    float m[3];
+    lstm_heads_valu<NH, 3>(NL.head_w, NL.vf_w, A, hn, lane, m);
+    const float hb = ok ? NL.head_b[lane] : 0.0f, ls = ok ? NL.logstd[lane] : 0.0f;
+    const float stdL = expf(ls), sumL = row16_sum(ls);
+    const float vb = NL.vf_b[0];
+    v0 = __shfl(m[0], 16) + vb; v1 = __shfl(m[1], 16) + vb;
+    const float n0 = ok ? r.noise0[nz] : 0.0f;
+    nlp0 = gauss_row(m[0] + hb, stdL, sumL, ok, true, n0, act0, A);      // the learner samples for agent 0 ...
+    onlp0 = gauss_row(mOB, stdO, sumO, ok, false, 0.0f, act0, A);        // ... the opponent net (zero state) scores that action
+    nlp1 = gauss_row(m[2] + hb, stdL, sumL, ok, false, 0.0f, act1, A);   // the learner (zero state) scores the opponent's action
+  }
+  if (ok) {
+    r.act[slot0 * A + lane] = act0; r.act[slot1 * A + lane] = act1;
+    float* ae = const_cast<float*>(a.actions) + (size_t)e * 2 * a.act_stride;
+    hand_store<true>(ae + lane, act0); hand_store<true>(ae + a.act_stride + lane, act1);
+    const sumo_model_t& mdl = c.P->mdl;
+    S(ctrl)[MI(agent_uadr)[0] + lane] = (double)act0; S(ctrl)[MI(agent_uadr)[1] + lane] = (double)act1;
+  }
+  if (lane == 0) {
+    r.nlp[slot0] = nlp0; r.nlp[slot1] = nlp1; r.onlp[slot0] = onlp0; r.onlp[slot1] = onlp1;
+    r.val[slot0] = v0; r.val[slot1] = v1;
+  }
+  wave_sync();
+}
+
 template <class C>
 __device__ __forceinline__ void rollout_post_phase(C& c, const StepArgs& a, const RolloutArgs& r, int e, int s) {
   SYNC();   // the step's reward inputs and episode record were parked in LDS by lane 0 of the epilogue
@@ -2312,7 +2440,7 @@ struct RolloutLaunch { StepArgs a; RolloutArgs r; };
 // launch's abort flag (counted in sumo_stats[9]) and every wave drains.
 #define ROLLOUT_SPIN_LIMIT (1u << 22)   /* polls of ~0.5 us each */
 
-template <int NV>
+template <int NV, int POLICY>   // POLICY 0: MLP(64,64) policy / value nets; 1: LSTM(128) with shared value head
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE_OF(NV), SUMO_WPE_OF(NV))))
 sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
   // `launch_args` is read in place from the kernel-argument segment (second argument, 8-byte aligned right behind P) through a
@@ -2354,7 +2482,8 @@ sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
     unsigned long long* prof = lp->r.prof;
     unsigned long long t0 = 0;
     if (prof && c.lane == 0) { t0 = wall_clock64(); if (k == 0) atomicExch(prof + 4 * e, t0); }
-    rollout_policy_phase(c, lp->a, lp->r, e, s);
+    if constexpr (POLICY == 1) rollout_policy_phase_lstm<128>(c, lp->a, lp->r, e, s);
+    else rollout_policy_phase(c, lp->a, lp->r, e, s);
     prof = launder_sptr(LP)->r.prof;
     if (prof && c.lane == 0) { const unsigned long long t1 = wall_clock64(); atomicAdd(prof + 4 * e + 2, t1 - t0); S(stash)[11] = __longlong_as_double((long long)t1); }
     env_step_body<true>(c, launder_sptr(LP)->a, e);
@@ -3086,20 +3215,63 @@ extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_d
   return 0;
 }
 
+// common tail of the two fused-rollout entry points: scheduler state, persistent grid, launch
+static int rollout_launch(sumo_engine* E, const RolloutArgs& r, int policy, float* actions_dev, float* obs_dev, double* info_dev,
+                          uint8_t* done_dev, double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream) {
+  RolloutLaunch rl;
+  rl.a = base_args(E);
+  StepArgs& a = rl.a;
+  a.actions = actions_dev; a.obs = obs_dev; a.info = info_dev; a.done = done_dev; a.ep_r = ep_r_dev; a.ep_dr = ep_dr_dev; a.ep_l = ep_l_dev;
+  rl.r = r;
+  rl.r.prof = E->d_trace;   // development: sumo_debug_trace(stamps) switches the per-wave phase clock on
+  hipStream_t st_ = (hipStream_t)stream;
+  if (!E->d_rsched) HIPCHK(hipMalloc((void**)&E->d_rsched, (size_t)(2 + E->N) * sizeof(int)));
+  HIPCHK(hipMemsetAsync(E->d_rsched, 0, (size_t)(2 + E->N) * sizeof(int), st_));
+  rl.r.sched = E->d_rsched;
+  // persistent waves: as many as the chip holds at this kernel's LDS footprint (8 per CU at most: two per SIMD)
+  int slots = (int)((size_t)160 * 1024 / (size_t)E->L.total_bytes);
+  if (slots > 4 * SUMO_WPE_OF(E->hm.nv)) slots = 4 * SUMO_WPE_OF(E->hm.nv);
+  if (slots < 1) slots = 1;
+  if (E->num_cus <= 0) {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, E->device));
+    E->num_cus = prop.multiProcessorCount;
+  }
+  long long nw = (long long)slots * E->num_cus;
+  if (nw > (long long)E->N) nw = E->N;   // more waves than envs would only wait on each other's steps
+  dim3 g_((unsigned)nw), b_(WAVE);
+  size_t lds_ = (size_t)E->L.total_bytes;
+  if (!for_kernel_variant(E->hm.nv, [&](auto nvc_) {
+        if (policy == 1) hipLaunchKernelGGL((sumo_rollout_kernel<decltype(nvc_)::value, 1>), g_, b_, lds_, st_, E->d_params, rl);
+        else hipLaunchKernelGGL((sumo_rollout_kernel<decltype(nvc_)::value, 0>), g_, b_, lds_, st_, E->d_params, rl);
+      }))
+    FAIL(-19, "no kernel variant for nv=%d", E->hm.nv);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// scene checks shared by the two entry points; returns the observation / action width through od / ad
+static int rollout_scene(sumo_engine* E, int T, int Ntot, int env_offset, int s0, int K, int* od, int* ad) {
+  const sumo_model_t* m = &E->hm;
+  const int* anq = SUMO_I(m, agent_nq); const int* anv = SUMO_I(m, agent_nv); const int* anb = SUMO_I(m, agent_nbody);
+  const int* anu = SUMO_I(m, agent_nu);
+  const int od0 = anq[0] + anv[0] + 6 * anb[0] + 14, od1 = anq[1] + anv[1] + 6 * anb[1] + 14;
+  if (od0 != od1 || anu[0] != anu[1]) FAIL(-3, "fused rollout needs a homogeneous match-up (one observation / action space for both sides, runner.py:14-16)");
+  if (T < 1 || K < 1 || s0 < 0 || s0 + K > T) FAIL(-5, "steps [%d, %d) outside the rollout buffers (T = %d)", s0, s0 + K, T);
+  if (env_offset < 0 || env_offset + E->N > Ntot) FAIL(-6, "envs [%d, %d) outside the rollout buffers (N = %d)", env_offset, env_offset + E->N, Ntot);
+  *od = od0; *ad = anu[0];
+  return 0;
+}
+
 extern "C" int sumo_rollout_steps(sumo_handle_t E, const sumo_rollout* ro, float* actions_dev, float* obs_dev, double* info_dev,
                                   uint8_t* done_dev, double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream) {
   if (!E || !ro || !actions_dev || !obs_dev || !info_dev || !done_dev || !ep_r_dev || !ep_dr_dev || !ep_l_dev) FAIL(-1, "bad arguments");
   if (!ro->learner_params || !ro->opponent_params || !ro->noise0 || !ro->noise1 || !ro->obs || !ro->act || !ro->rew || !ro->val ||
       !ro->nlp || !ro->onlp || !ro->done || !ro->ep_done || !ro->ep_r || !ro->ep_l)
     FAIL(-2, "sumo_rollout: missing buffer");
-  const sumo_model_t* m = &E->hm;
-  const int* anq = SUMO_I(m, agent_nq); const int* anv = SUMO_I(m, agent_nv); const int* anb = SUMO_I(m, agent_nbody);
-  const int* anu = SUMO_I(m, agent_nu);
-  const int od0 = anq[0] + anv[0] + 6 * anb[0] + 14, od1 = anq[1] + anv[1] + 6 * anb[1] + 14;
-  if (od0 != od1 || anu[0] != anu[1]) FAIL(-3, "fused rollout needs a homogeneous match-up (one observation / action space for both sides, runner.py:14-16)");
-  if (ro->ob_dim != od0 || ro->ac_dim != anu[0] || ro->ac_dim > PT_MAXA) FAIL(-4, "ob_dim %d / ac_dim %d do not match the scene (%d / %d)", ro->ob_dim, ro->ac_dim, od0, anu[0]);
-  if (ro->T < 1 || ro->K < 1 || ro->s0 < 0 || ro->s0 + ro->K > ro->T) FAIL(-5, "steps [%d, %d) outside the rollout buffers (T = %d)", ro->s0, ro->s0 + ro->K, ro->T);
-  if (ro->env_offset < 0 || ro->env_offset + E->N > ro->Ntot) FAIL(-6, "envs [%d, %d) outside the rollout buffers (N = %d)", ro->env_offset, ro->env_offset + E->N, ro->Ntot);
+  int od = 0, ad = 0;
+  if (int rc = rollout_scene(E, ro->T, ro->Ntot, ro->env_offset, ro->s0, ro->K, &od, &ad)) return rc;
+  if (ro->ob_dim != od || ro->ac_dim != ad || ro->ac_dim > PT_MAXA) FAIL(-4, "ob_dim %d / ac_dim %d do not match the scene (%d / %d)", ro->ob_dim, ro->ac_dim, od, ad);
   if (ro->npool < 1) FAIL(-7, "npool %d", ro->npool);
   HIPCHK(hipSetDevice(E->device));
   RolloutArgs r;
@@ -3109,39 +3281,43 @@ extern "C" int sumo_rollout_steps(sumo_handle_t E, const sumo_rollout* ro, float
   r.ep_done = ro->ep_done; r.ep_r = ro->ep_r; r.ep_l = ro->ep_l; r.alpha = ro->alpha;
   r.T = ro->T; r.Ntot = ro->Ntot; r.env_offset = ro->env_offset; r.s0 = ro->s0; r.K = ro->K;
   r.XS = x_stride(ro->ob_dim); r.L = make_layout(ro->ob_dim, ro->ac_dim); r.lds_off = E->L.M;
-  r.prof = E->d_trace;   // development: sumo_debug_trace(stamps) switches the per-wave phase clock on
   if ((size_t)(2 * r.XS + 4 * PT_HS) * sizeof(float) > (size_t)E->L.msize * sizeof(double))
     FAIL(-8, "policy scratch (%zu B) does not fit the mass-matrix region (%zu B)", (size_t)(2 * r.XS + 4 * PT_HS) * sizeof(float), (size_t)E->L.msize * sizeof(double));
-  RolloutLaunch rl;
-  rl.a = base_args(E);
-  StepArgs& a = rl.a;
-  a.actions = actions_dev; a.obs = obs_dev; a.info = info_dev; a.done = done_dev; a.ep_r = ep_r_dev; a.ep_dr = ep_dr_dev; a.ep_l = ep_l_dev;
-  rl.r = r;
-  hipStream_t st_ = (hipStream_t)stream;
-  if (!E->d_rsched) HIPCHK(hipMalloc((void**)&E->d_rsched, (size_t)(2 + E->N) * sizeof(int)));
-  HIPCHK(hipMemsetAsync(E->d_rsched, 0, (size_t)(2 + E->N) * sizeof(int), st_));
-  rl.r.sched = E->d_rsched;
-  {
-    // persistent waves: as many as the chip holds at this kernel's LDS footprint (8 per CU at most: two per SIMD)
-    int slots = (int)((size_t)160 * 1024 / (size_t)E->L.total_bytes);
-    if (slots > 4 * SUMO_WPE_OF(E->hm.nv)) slots = 4 * SUMO_WPE_OF(E->hm.nv);
-    if (slots < 1) slots = 1;
-    if (E->num_cus <= 0) {
-      hipDeviceProp_t prop;
-      HIPCHK(hipGetDeviceProperties(&prop, E->device));
-      E->num_cus = prop.multiProcessorCount;
-    }
-    long long nw = (long long)slots * E->num_cus;
-    if (nw > (long long)E->N) nw = E->N;   // more waves than envs would only wait on each other's steps
-    dim3 g_((unsigned)nw), b_(WAVE);
-    size_t lds_ = (size_t)E->L.total_bytes;
-    if (!for_kernel_variant(E->hm.nv, [&](auto nvc_) {
-          hipLaunchKernelGGL(sumo_rollout_kernel<decltype(nvc_)::value>, g_, b_, lds_, st_, E->d_params, rl);
-        }))
-      FAIL(-19, "no kernel variant for nv=%d", E->hm.nv);
-  }
-  HIPCHK(hipGetLastError());
-  return 0;
+  return rollout_launch(E, r, 0, actions_dev, obs_dev, info_dev, done_dev, ep_r_dev, ep_dr_dev, ep_l_dev, stream);
+}
+
+extern "C" int sumo_rollout_steps_lstm(sumo_handle_t E, const sumo_rollout_lstm* ro, float* actions_dev, float* obs_dev, double* info_dev,
+                                       uint8_t* done_dev, double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream) {
+  if (!E || !ro || !actions_dev || !obs_dev || !info_dev || !done_dev || !ep_r_dev || !ep_dr_dev || !ep_l_dev) FAIL(-1, "bad arguments");
+  if (!ro->learner || !ro->opponents_dev || !ro->state0 || !ro->state1 || !ro->noise0 || !ro->noise1 || !ro->obs || !ro->act || !ro->rew ||
+      !ro->val || !ro->nlp || !ro->onlp || !ro->done || !ro->ep_done || !ro->ep_r || !ro->ep_l)
+    FAIL(-2, "sumo_rollout_lstm: missing buffer");
+  int od = 0, ad = 0;
+  if (int rc = rollout_scene(E, ro->T, ro->Ntot, ro->env_offset, ro->s0, ro->K, &od, &ad)) return rc;
+  const ppo_lstm_net& n = *ro->learner;
+  if (n.ob_dim != od || n.ac_dim != ad || n.ac_dim > PT_MAXA) FAIL(-4, "ob_dim %d / ac_dim %d do not match the scene (%d / %d)", n.ob_dim, n.ac_dim, od, ad);
+  // what the in-wave evaluation is built for: the nets `learn(network='lstm')` trains (policy-zoo LSTM nets carry an observation
+  // filter, an embedding and the other gate order: they go through ppo_lstm_step)
+  if (n.hidden != 128 || n.gate_order != PPO_LSTM_GATES_IFOU || n.emb_w || n.emb_dim != 0 || n.obs_mean || n.obs_invstd)
+    FAIL(-9, "fused recurrent rollout: hidden 128, gate order i,f,o,u, no embedding, no observation filter (got hidden %d, order %d, emb %d)", n.hidden, n.gate_order, n.emb_dim);
+  if (!n.wx || !n.wh || !n.b || !n.head_w || !n.head_b || !n.logstd || !n.vf_w || !n.vf_b) FAIL(-10, "learner net: missing weights");
+  if (ro->npool < 1) FAIL(-7, "npool %d", ro->npool);
+  if (ro->tile_net_dev && ((ro->env_offset & 15) || (E->N & 15))) FAIL(-11, "a snapshot per 16-env tile needs env_offset (%d) and the env count (%d) to be multiples of 16", ro->env_offset, E->N);
+  HIPCHK(hipSetDevice(E->device));
+  RolloutArgs r;
+  memset(&r, 0, sizeof r);
+  r.lnet = n; r.onets = ro->opponents_dev; r.tile_net = ro->tile_net_dev; r.st0 = ro->state0; r.st1 = ro->state1;
+  r.noise0 = ro->noise0; r.noise1 = ro->noise1;
+  r.obs = ro->obs; r.act = ro->act; r.rew = ro->rew; r.val = ro->val; r.nlp = ro->nlp; r.onlp = ro->onlp; r.done = ro->done;
+  r.ep_done = ro->ep_done; r.ep_r = ro->ep_r; r.ep_l = ro->ep_l; r.alpha = ro->alpha;
+  r.T = ro->T; r.Ntot = ro->Ntot; r.env_offset = ro->env_offset; r.s0 = ro->s0; r.K = ro->K;
+  r.XS = (od + 3) & ~3;
+  // between two steps of an env nothing from the mass matrix to the end of the float64 area is live (contact records, Jacobian
+  // pool and row arrays are rebuilt by every forward): the phase's rows go there, 16-byte aligned for the 128-bit LDS reads
+  r.lds_off = (E->L.M + 1) & ~1;
+  const size_t need = (size_t)(2 * r.XS + 7 * 128) * sizeof(float), have = (size_t)(E->L.i_base - r.lds_off) * sizeof(double);
+  if (E->L.ctrl >= E->L.M || E->L.stash >= E->L.M || need > have) FAIL(-8, "policy scratch (%zu B) does not fit the per-step LDS area (%zu B)", need, have);
+  return rollout_launch(E, r, 1, actions_dev, obs_dev, info_dev, done_dev, ep_r_dev, ep_dr_dev, ep_l_dev, stream);
 }
 
 extern "C" int sumo_debug_trace(sumo_handle_t E, uint64_t* stamps_dev) {

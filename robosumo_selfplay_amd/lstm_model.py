@@ -28,6 +28,7 @@ class LstmSpec(object):
 class LstmPPOModel(object):
     loss_names = ["policy_loss", "value_loss", "policy_entropy", "approxkl", "clipfrac"]
     recurrent = True
+    accepts_noise = True  # step(..., noise=rows) takes the action noise from the caller (device-mode Runner: one draw per rollout)
     use_graph = True      # single-GPU training on device tensors: the ~2T+12 launches of a minibatch step replay from a HIP graph
 
     def __init__(self, *, policy, ob_space=None, ac_space=None, nbatch_act=None, nbatch_train=None, nsteps=None, ent_coef=0.0,
@@ -115,7 +116,14 @@ class LstmPPOModel(object):
         t = self._t
         return x if t.is_tensor(x) else t.from_numpy(np.ascontiguousarray(x, dtype)).to(self.device)
 
-    def _run(self, obs, S, M, given_action=None, deterministic=False):
+    def net_dev(self):
+        """Device copy of this model's ``ppo_lstm_net`` (its pointers address ``self.params``, whose storage never moves): what the
+        fused recurrent rollout reads when this model is the opponent."""
+        if getattr(self, "_net_dev", None) is None:
+            self._net_dev = self._t.from_numpy(np.frombuffer(bytes(self._net), dtype=np.uint8).copy()).to(self.device)
+        return self._net_dev
+
+    def _run(self, obs, S, M, given_action=None, deterministic=False, noise=None):
         t = self._t
         np_in = not t.is_tensor(obs)
         D, A, H = self.spec.ob_dim, self.spec.ac_dim, self.spec.nlstm
@@ -127,7 +135,10 @@ class LstmPPOModel(object):
         neglogp = t.empty(n, dtype=t.float32, device=self.device)
         value = t.empty(n, dtype=t.float32, device=self.device)
         given = None if given_action is None else self._dev(given_action).reshape(n, A).contiguous()
-        noise = None if (deterministic or given is not None) else t.randn((n, A), generator=self.gen, device=self.device, dtype=t.float32)
+        if deterministic or given is not None:
+            noise = None
+        elif noise is None:                       # (the device-mode Runner hands in the rows of a per-rollout draw instead)
+            noise = t.randn((n, A), generator=self.gen, device=self.device, dtype=t.float32)
         ppo_capi.chk(ppo_capi.lib().ppo_lstm_step(C.byref(self._net), x.data_ptr(), n, x.stride(0) if n > 1 else D, ppo_capi.ptr(mask),
                                                   st.data_ptr(), st.data_ptr() + 4 * H, 2 * H, ppo_capi.ptr(noise), ppo_capi.ptr(given),
                                                   action.data_ptr(), neglogp.data_ptr(), value.data_ptr(), None,
@@ -135,8 +146,8 @@ class LstmPPOModel(object):
         out = (lambda z: z.cpu().numpy()) if np_in else (lambda z: z)
         return out(action), out(value), out(st), out(neglogp)
 
-    def step(self, observation, S=None, M=None, deterministic=False, **extra_feed):
-        return self._run(observation, S, M, deterministic=deterministic)
+    def step(self, observation, S=None, M=None, deterministic=False, noise=None, **extra_feed):
+        return self._run(observation, S, M, deterministic=deterministic, noise=noise)
 
     def value(self, ob, S=None, M=None, **kwargs):
         return self._run(ob, S, M, deterministic=True)[1]

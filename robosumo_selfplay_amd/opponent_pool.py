@@ -76,6 +76,7 @@ class LstmOpponentPool(object):
     snapshot, all tiles in ONE launch (``ppo_lstm_step_pool``).  The snapshot index is per tile of 16 consecutive envs (an MFMA
     tile shares its weight operands), so ``assign`` takes ``num_envs / 16`` entries; ``index`` expands it per env."""
     recurrent = True
+    accepts_noise = True
 
     def __init__(self, spec, capacity, num_envs, device):
         import ctypes as C
@@ -152,7 +153,7 @@ class LstmOpponentPool(object):
     def counts(self):
         return np.bincount(self.tile_net.cpu().numpy(), minlength=self.capacity) * 16
 
-    def _run(self, obs, S, M, given_action=None, deterministic=False, first_env=0):
+    def _run(self, obs, S, M, given_action=None, deterministic=False, first_env=0, noise=None):
         t, C, cap = self._t, self._C, self._capi
         D, A, H = self.spec.ob_dim, self.spec.ac_dim, self.spec.nlstm
         if not t.is_tensor(obs):
@@ -167,7 +168,10 @@ class LstmOpponentPool(object):
         neglogp = t.empty(n, dtype=t.float32, device=self.device)
         value = t.empty(n, dtype=t.float32, device=self.device)
         given = None if given_action is None else given_action.reshape(n, A).contiguous()
-        noise = None if (deterministic or given is not None) else t.randn((n, A), generator=self.gen, device=self.device, dtype=t.float32)
+        if deterministic or given is not None:
+            noise = None
+        elif noise is None:
+            noise = t.randn((n, A), generator=self.gen, device=self.device, dtype=t.float32)
         tiles = self.tile_net[first_env // 16:(first_env + n) // 16]
         cap.chk(cap.lib().ppo_lstm_step_pool(C.byref(self._proto), self._nets_dev.data_ptr(), tiles.data_ptr(), x.data_ptr(), n,
                                              x.stride(0) if n > 1 else D, cap.ptr(mask), st.data_ptr(), st.data_ptr() + 4 * H, 2 * H,
@@ -176,8 +180,8 @@ class LstmOpponentPool(object):
         return action, value, st, neglogp
 
     # the Runner's recurrent device path evaluates one env group at a time: ``first_env`` names the group's first env
-    def step(self, observation, S=None, M=None, deterministic=False, first_env=0, **extra_feed):
-        return self._run(observation, S, M, deterministic=deterministic, first_env=first_env)
+    def step(self, observation, S=None, M=None, deterministic=False, first_env=0, noise=None, **extra_feed):
+        return self._run(observation, S, M, deterministic=deterministic, first_env=first_env, noise=noise)
 
     def value(self, ob, S=None, M=None, first_env=0, **kwargs):
         return self._run(ob, S, M, deterministic=True, first_env=first_env)[1]

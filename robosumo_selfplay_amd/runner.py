@@ -192,6 +192,68 @@ class Runner(AbstractEnvRunner):
                 st.wait_stream(cur)
         return self._gstreams
 
+    def _draw_steps(self, gen, T, n, A):
+        """Action noise [T, n, A] as T consecutive [n, A] draws of ``gen``: what ``step`` would draw call by call (so a one-group
+        device rollout consumes the generator exactly like the reference-order host rollout)."""
+        t = self._t
+        buf = t.empty((T, n, A), dtype=t.float32, device=self.device)
+        for k in range(T):
+            t.randn((n, A), generator=gen, device=self.device, dtype=t.float32, out=buf[k])
+        return buf
+
+    def fused_lstm_ok(self):
+        """The fused recurrent launch (``sumo_rollout_steps_lstm``) applies to device mode with the nets ``learn(network='lstm')``
+        trains on both sides -- an ``LstmPPOModel`` learner against an ``LstmPPOModel`` or an ``LstmOpponentPool`` -- with
+        nlstm = 128 and the env's own observation / action shape."""
+        from .lstm_model import LstmPPOModel
+        from .opponent_pool import LstmOpponentPool
+        env = self.env
+        if not (self.device_mode and self.fused_rollout and self.recurrent and hasattr(env, "rollout_steps_lstm_group")):
+            return False
+        m0, m1 = self.models[0], self.models[1]
+        if type(m0) is not LstmPPOModel or type(m1) not in (LstmPPOModel, LstmOpponentPool):
+            return False
+        sp0, sp1 = m0.spec, m1.spec
+        if isinstance(m1, LstmOpponentPool) and (m1.num_envs != self.nenv or any((env._gs(g).start % 16 or env._gs(g).stop % 16)
+                                                                                 for g in range(getattr(env, "groups", 1)))):
+            return False
+        return (sp0.nlstm == sp1.nlstm == 128 and sp0.ob_dim == sp1.ob_dim == self.ob_dim and sp0.ac_dim == sp1.ac_dim
+                and env.act_dev.shape[2] == sp0.ac_dim and env.obs_dev.stride(2) == 1)
+
+    def _steps_fused_lstm(self, B, s0, K, alpha):
+        """``_steps_fused`` for recurrent policies: one ``sumo_rollout_steps_lstm`` launch per env group; the recurrent states
+        ``self.states`` are advanced in place.  Same numbers as the step-by-step recurrent branch of ``_step_group``."""
+        import ctypes as C
+        from . import capi
+        from .opponent_pool import LstmOpponentPool
+        t = self._t
+        env = self.env
+        m0, m1 = self.models
+        G = getattr(env, "groups", 1)
+        streams = self._group_streams() if G > 1 else [None]
+        A, T, N = m0.spec.ac_dim, B["T"], self.nenv
+        for g in range(G):
+            sl = env._gs(g)
+            n = sl.stop - sl.start
+            ctx = t.cuda.stream(streams[g]) if streams[g] is not None else _nullctx()
+            with ctx:
+                key = ("noise", sl.start)
+                if s0 == 0 or key not in B:
+                    B[key] = (self._draw_steps(m0.gen, T, n, A), self._draw_steps(m1.gen, T, n, A))
+                ro = capi.RolloutLstm()
+                ro.learner = C.addressof(m0._net)
+                if isinstance(m1, LstmOpponentPool):
+                    ro.opponents_dev, ro.tile_net_dev, ro.npool = m1._nets_dev.data_ptr(), m1.tile_net.data_ptr(), m1.capacity
+                else:
+                    ro.opponents_dev, ro.tile_net_dev, ro.npool = m1.net_dev().data_ptr(), None, 1
+                ro.state0, ro.state1 = self.states[0][sl].data_ptr(), self.states[1][sl].data_ptr()
+                ro.T, ro.Ntot, ro.env_offset, ro.s0, ro.K, ro.alpha = T, N, sl.start, int(s0), int(K), float(alpha)
+                ro.noise0, ro.noise1 = B[key][0].data_ptr(), B[key][1].data_ptr()
+                for f in ("obs", "act", "rew", "val", "nlp", "onlp", "done", "ep_done", "ep_r", "ep_l"):
+                    setattr(ro, f, B[f].data_ptr())
+                env.rollout_steps_lstm_group(g, ro)
+        self.obs, self.dones = env.obs_dev, env.done_dev
+
     def fused_ok(self):
         """The fused rollout launch applies to device mode with two plain MLP policies of the env's own observation / action shape."""
         if not (self.device_mode and self.fused_rollout and not self.recurrent and hasattr(self.env, "rollout_steps_group")):
@@ -263,12 +325,20 @@ class Runner(AbstractEnvRunner):
             # same five evaluations through the recurrent nets (runner.py:62-96 with the S / M feeds): each stream carries its
             # acting model's state; the scoring calls without a state feed start from zeros, as the reference's calls do
             m0, m1 = self.models
-            a0, v0, S0, n0 = m0.step(o0, S=self.states[0][sl], M=dn[:, 0])
+            nk0, nk1 = {}, {}
+            if getattr(m0, "accepts_noise", False) and getattr(m1, "accepts_noise", False):
+                # action noise of this group for the whole buffer, drawn at its first step from each acting model's generator
+                # (as the MLP path does): the fused recurrent launch consumes the same draws
+                key = ("noise", sl.start)
+                if s == 0 or key not in B:
+                    B[key] = (self._draw_steps(m0.gen, B["T"], n, act0.shape[-1]), self._draw_steps(m1.gen, B["T"], n, act0.shape[-1]))
+                nk0, nk1 = dict(noise=B[key][0][s]), dict(noise=B[key][1][s])
+            a0, v0, S0, n0 = m0.step(o0, S=self.states[0][sl], M=dn[:, 0], **nk0)
             self.states[0][sl] = S0
             act0.copy_(a0); B["val"][0, s, sl].copy_(v0); B["nlp"][0, s, sl].copy_(n0)
             pk = dict(first_env=sl.start) if hasattr(m1, "tile_net") else {}      # opponent pool: snapshots are indexed per env tile
             B["onlp"][0, s, sl].copy_(m1.act_model.action_probability(o0, given_action=a0, **pk))
-            a1, _, S1, on1 = m1.step(o1, S=self.states[1][sl], M=dn[:, 1], **pk)
+            a1, _, S1, on1 = m1.step(o1, S=self.states[1][sl], M=dn[:, 1], **pk, **nk1)
             self.states[1][sl] = S1
             act1.copy_(a1); B["onlp"][1, s, sl].copy_(on1)
             B["val"][1, s, sl].copy_(m0.value(o1, S=S1, M=dn[:, 1]))
@@ -365,10 +435,11 @@ class Runner(AbstractEnvRunner):
             cur = t.cuda.current_stream(self.device)
             for st in self._gstreams:
                 st.wait_stream(cur)
-        if self.fused_ok():
+        if self.fused_ok() or self.fused_lstm_ok():
+            steps = self._steps_fused_lstm if self.recurrent else self._steps_fused
             chunk = self.rollout_chunk if self.rollout_chunk > 0 else T
             for s0 in range(0, T, chunk):
-                self._steps_fused(B, s0, min(chunk, T - s0), alpha)
+                steps(B, s0, min(chunk, T - s0), alpha)
         else:
             if self.opponent_pool is not None:
                 raise NotImplementedError("a per-env opponent pool needs the fused rollout path (MLP policies, SUMO_FUSED_ROLLOUT != 0)")

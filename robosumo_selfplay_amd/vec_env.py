@@ -139,6 +139,13 @@ class SumoVecEnv(VecEnv):
                                       self.done_dev[sl].data_ptr(), self.ep_r_dev[sl].data_ptr(), self.ep_dr_dev[sl].data_ptr(),
                                       self.ep_l_dev[sl].data_ptr(), stream=self._stream())
 
+    def rollout_steps_lstm_group(self, g, ro):
+        """The same for recurrent policies (``capi.Engine.rollout_steps_lstm``, ``ro`` a ``capi.RolloutLstm``)."""
+        sl = self._gs(g)
+        self.engines[g].rollout_steps_lstm(ro, self.act_dev[sl].data_ptr(), self.obs_dev[sl].data_ptr(), self.info_dev[sl].data_ptr(),
+                                           self.done_dev[sl].data_ptr(), self.ep_r_dev[sl].data_ptr(), self.ep_dr_dev[sl].data_ptr(),
+                                           self.ep_l_dev[sl].data_ptr(), stream=self._stream())
+
     def step_device(self, actions):
         """actions: float32 CUDA tensor [N, 2, act_stride]. Returns (obs, info, done, ep_r, ep_dr, ep_l) tensors that
         are overwritten by the next call."""
