@@ -15,6 +15,21 @@
 #define PT_WAVE 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Global-memory pointers.  A pointer the compiler cannot trace to a kernel argument (one read from a struct in memory: a net
+// description, the laundered launch arguments of the rollout kernel) is a GENERIC pointer and its loads are flat_load, which
+// occupy the LDS counter as well as the vector-memory counter: every wait for an LDS read then also waits for the weight loads in
+// flight, and a loop that interleaves both runs one memory round trip per iteration whatever the prefetch depth.  Loads through
+// an address_space(1) pointer are global_load (vmcnt only).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_GAS __attribute__((address_space(1)))
+#define PT_CAS __attribute__((address_space(4)))   /* constant memory (the kernel-argument segment): scalar loads */
+#else   /* the host pass parses the device functions too, and has no address spaces */
+#define PT_GAS
+#define PT_CAS
+#endif
+template <class T> __device__ __forceinline__ const T PT_GAS* pt_global(const T* p) { return (const T PT_GAS*)p; }
+template <class T> __device__ __forceinline__ T PT_GAS* pt_global(T* p) { return (T PT_GAS*)p; }
 #define PT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 struct ParamLayout {  // offsets into the flat parameter vector (checkpoint order)
@@ -43,7 +58,7 @@ static int x_stride(int D) {  // LDS row stride of the staged observation tile: 
 // ---------------------------------------------------------------------------------------------------------
 // shared device pieces: one wave, one 16-row tile, one trunk
 // ---------------------------------------------------------------------------------------------------------
-struct Net { const float *w0, *b0, *w1, *b1, *w2, *b2; int nout; };
+struct Net { const float PT_GAS *w0, *b0, *w1, *b1, *w2, *b2; int nout; };
 
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
@@ -136,11 +151,15 @@ __device__ __forceinline__ float kq_sum(float v) {  // sum over the 4 lanes that
   return v;
 }
 
-__device__ __forceinline__ Net pi_net(const float* p, const ParamLayout& L) {
+template <class PL>   // ParamLayout in any address space (the rollout kernel reads it in place from its kernel-argument segment)
+__device__ __forceinline__ Net pi_net(const float* p_, const PL& L) {
+  const float PT_GAS* p = pt_global(p_);
   Net n = {p + L.pi_w0, p + L.pi_b0, p + L.pi_w1, p + L.pi_b1, p + L.pi_w, p + L.pi_b, L.A};
   return n;
 }
-__device__ __forceinline__ Net vf_net(const float* p, const ParamLayout& L) {
+template <class PL>
+__device__ __forceinline__ Net vf_net(const float* p_, const PL& L) {
+  const float PT_GAS* p = pt_global(p_);
   Net n = {p + L.vf_w0, p + L.vf_b0, p + L.vf_w1, p + L.vf_b1, p + L.vf_w, p + L.vf_b, 1};
   return n;
 }
@@ -157,8 +176,10 @@ __device__ __forceinline__ float gauss_row(float m, float std, float sum_logstd,
 
 // Gaussian head on a policy tile (D layout): samples (noise != nullptr) or scores `act`; returns the row's neglogp in
 // the lanes with i == 0 via nlp[r]
-__device__ __forceinline__ void gauss_head(const float* params, const ParamLayout& L, const f32x4& mean, const float* noise, int r0, int n,
+__device__ __forceinline__ void gauss_head(const float* params_, const ParamLayout& L, const f32x4& mean, const float* noise_, int r0, int n,
                                            int lane, float (&act)[4], float (&nlp)[4]) {
+  const float PT_GAS* params = pt_global(params_);
+  const float PT_GAS* noise = pt_global(noise_);
   const int i = lane & 15, kq = lane >> 4, A = L.A;
   const bool col = i < A;
   const float logstd = col ? params[L.logstd + i] : 0.0f;
@@ -214,15 +235,15 @@ __device__ __forceinline__ void lstm_gates_valu(const float* wx, const float* wh
     for (int r = 0; r < R; r++) { z[g][0][r] = 0.0f; z[g][1][r] = 0.0f; }
   auto fetch = [&](int ch, f32x2u (&w)[4][4]) {
     const bool in_x = ch < nx;
-    const float* base = in_x ? wx : wh;
+    const float PT_GAS* base = pt_global(in_x ? wx : wh);
     const int k0 = 4 * (in_x ? ch : ch - nx), kmax = in_x ? D : NH;
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
       int k = k0 + kk;
       if (k >= kmax) k = kmax - 1;   // the x rows are zero there: fma(0, w, z) == z for any finite weight
-      const float* wrow = base + (size_t)k * 4 * NH + col;
+      const float PT_GAS* wrow = base + (size_t)k * 4 * NH + col;
 #pragma unroll
-      for (int g = 0; g < 4; g++) w[kk][g] = *(const f32x2u*)(wrow + g * NH);
+      for (int g = 0; g < 4; g++) w[kk][g] = *(const f32x2u PT_GAS*)(wrow + g * NH);
     }
   };
   auto consume = [&](int ch, const f32x2u (&w)[4][4]) {
@@ -241,31 +262,41 @@ __device__ __forceinline__ void lstm_gates_valu(const float* wx, const float* wh
         }
     }
   };
-  f32x2u w0[4][4], w1[4][4];   // the loads of chunk c + 1 are in flight during the products of chunk c
-  fetch(0, w0);
-  for (int ch = 0; ch < nch; ch += 2) {
-    if (ch + 1 < nch) fetch(ch + 1, w1);
-    consume(ch, w0);
-    if (ch + 2 < nch) fetch(ch + 2, w0);
-    if (ch + 1 < nch) consume(ch + 1, w1);
+  // a chunk costs one trip to the L2 / MALL (~0.8 us under load) unless enough of them are in flight: ring of four chunk buffers,
+  // three chunks (48 loads, 24 KB per wave) ahead of the products
+  f32x2u w[4][4][4];
+  fetch(0, w[0]); fetch(1, w[1]); fetch(2, w[2]);
+  int ch = 0;
+  for (; ch + 4 <= nch; ch += 4) {
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int nxt = ch + b + 3;
+      fetch(nxt < nch ? nxt : nch - 1, w[(b + 3) & 3]);   // (no branch around the loads: past the end the last chunk is fetched again)
+      consume(ch + b, w[b]);
+    }
   }
+#pragma unroll
+  for (int b = 0; b < 3; b++)   // the last nch % 4 chunks are in flight in buffers 0 .. 2
+    if (ch + b < nch) consume(ch + b, w[b]);
 }
 
 // Heads on R latent rows in LDS (hn [R][NH]): lane i < A accumulates column i of the Gaussian mean, lane 16 the value, over the
 // units in ascending order (the k order of the head tiles of ppo_lstm_step_kernel); biases are added by the caller.
 template <int NH, int R>
-__device__ __forceinline__ void lstm_heads_valu(const float* head_w, const float* vf_w, int A, const float* hn, int lane, float (&acc)[R]) {
+__device__ __forceinline__ void lstm_heads_valu(const float* head_w_, const float* vf_w_, int A, const float* hn, int lane, float (&acc)[R]) {
+  const float PT_GAS* head_w = pt_global(head_w_);
+  const float PT_GAS* vf_w = pt_global(vf_w_);
   const bool pi = lane < A, vf = lane == 16;
 #pragma unroll
   for (int r = 0; r < R; r++) acc[r] = 0.0f;
-  for (int j0 = 0; j0 < NH; j0 += 16) {
-    float w[16];
+  for (int j0 = 0; j0 < NH; j0 += 64) {   // 64 weight loads in flight: two trips to the L2 per head instead of one per 16 units
+    float w[64];
 #pragma unroll
-    for (int u = 0; u < 16; u++) w[u] = pi ? head_w[(j0 + u) * A + lane] : (vf ? vf_w[j0 + u] : 0.0f);
+    for (int u = 0; u < 64; u++) w[u] = pi ? head_w[(j0 + u) * A + lane] : (vf ? vf_w[j0 + u] : 0.0f);
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
+      for (int q = 0; q < 16; q++) {
         const float4 hv = *(const float4*)(hn + r * NH + j0 + 4 * q);
         acc[r] = __builtin_fmaf(hv.x, w[4 * q], acc[r]); acc[r] = __builtin_fmaf(hv.y, w[4 * q + 1], acc[r]);
         acc[r] = __builtin_fmaf(hv.z, w[4 * q + 2], acc[r]); acc[r] = __builtin_fmaf(hv.w, w[4 * q + 3], acc[r]);

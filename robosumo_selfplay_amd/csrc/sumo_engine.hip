@@ -123,9 +123,9 @@ struct StepArgs {
   int* dbg_counts;
 };
 
-#define MI(name) (mdl.ibase + mdl.o_##name)
-#define MF(name) (mdl.fbase + mdl.o_##name)
-#define AI(name) (aux.ai + aux.o_##name)
+#define MI(name) (pt_global(mdl.ibase) + mdl.o_##name)
+#define MF(name) (pt_global(mdl.fbase) + mdl.o_##name)
+#define AI(name) (pt_global(aux.ai) + aux.o_##name)
 
 /* One wavefront per workgroup: LDS operations of a wave are issued and completed in order, so phases only need a
  * compiler barrier between them (no s_waitcnt drain of unrelated loads, no s_barrier). */
@@ -433,9 +433,21 @@ struct Ctx {
 // within 256 registers, i.e. two waves per SIMD.
 template <class T>
 __device__ __forceinline__ const T* launder_ptr(const T* p) { asm volatile("" : "+v"(p)); return p; }
+template <class PTR>
+__device__ __forceinline__ PTR launder_sptr(PTR p) { asm volatile("" : "+s"(p)); return p; }   // wave-uniform pointer (SGPR pair), any address space
+// a record of a constant table, read through a global-address-space pointer dword by dword (only the fields that are used
+// survive; a laundered pointer is a generic one, whose flat loads would occupy the LDS counter too -- see PT_GAS in ppo_tile.h)
 template <class T>
-__device__ __forceinline__ const T* launder_sptr(const T* p) { asm volatile("" : "+s"(p)); return p; }   // wave-uniform pointer (SGPR pair)
-#define KCONSTS() const LaneRec K = *launder_ptr(c.kp)
+__device__ __forceinline__ T load_rec(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "whole dwords");
+  T out;
+  const uint32_t PT_GAS* s_ = (const uint32_t PT_GAS*)p;
+  uint32_t* d_ = (uint32_t*)&out;
+#pragma unroll
+  for (unsigned i_ = 0; i_ < sizeof(T) / 4; i_++) d_[i_] = s_[i_];
+  return out;
+}
+#define KCONSTS() const LaneRec K = load_rec(launder_ptr(c.kp))
 // mass matrix element (i, j) of the block-diagonal storage; valid when i and j belong to the same agent tree
 #define MIDX(i, j) ((i) * c.L.mld + ((j) >= c.L.d1 ? (j) - c.L.d1 : (j)))
 #define SAME_TREE(i, j) (((i) >= c.L.d1) == ((j) >= c.L.d1))
@@ -547,7 +559,7 @@ __device__ __forceinline__ void position_velocity(C& c) {
   SYNC();
   PROF(0);
   {
-    const int my_level = launder_ptr(c.kp)->b_level;
+    const int my_level = pt_global(launder_ptr(c.kp))->b_level;
     for (int lvl = 1; lvl < aux.ndepth; lvl++) {
       if (my_level == lvl) kin_own_body(c);
       SYNC();
@@ -740,7 +752,7 @@ __device__ __forceinline__ void position_velocity(C& c) {
   }
   SYNC();
   gather_up<6>(c, S(cfrc));
-  if (lane < nv) S(bias)[lane] = dot6(S(cdof) + 6 * lane, S(cfrc) + 6 * launder_ptr(c.kp)->d_body);
+  if (lane < nv) S(bias)[lane] = dot6(S(cdof) + 6 * lane, S(cfrc) + 6 * pt_global(launder_ptr(c.kp))->d_body);
   PROF(3);
 }
 
@@ -794,8 +806,8 @@ __device__ __forceinline__ void mass_matrix(C& c) {
 #define STAT_I(k) (c.si[c.L.stat_i + (k)])
 #define STAT_D(k) (c.sm + c.L.stat_d + (k))
 #else
-#define STAT_I(k) (c.P->aux.ai[c.P->aux.o_stat_i + (k)])
-#define STAT_D(k) (c.P->aux.af + c.P->aux.o_stat_d + (k))
+#define STAT_I(k) (pt_global(c.P->aux.ai)[c.P->aux.o_stat_i + (k)])
+#define STAT_D(k) (pt_global(c.P->aux.af) + c.P->aux.o_stat_d + (k))
 #endif
 #define CTYPE(ci) STAT_I(ci)
 #define CBODY(ci) STAT_I(c.P->aux.nc + (ci))
@@ -834,8 +846,8 @@ __device__ __forceinline__ void collision(C& c) {
   int base = 0, total = 0;
   do {
     int run = 0;
-    const int* prp = launder_ptr(c.prp);
-    const float* pbp = launder_ptr(c.pbp);
+    const int PT_GAS* prp = pt_global(launder_ptr(c.prp));
+    const float PT_GAS* pbp = pt_global(launder_ptr(c.pbp));
     // ---- world pairs: distance from the moving geom's centre to the static geom's extent (box / segment / half space)
     for (int r0 = 0; r0 < WR; r0 += 4) {
       int rec[4], pass[4];
@@ -1599,7 +1611,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
       int pi[C::EPL], pj[C::EPL];   // chain positions of the entry's two dofs (slot lookup, SLOT_OF)
 #pragma unroll
       for (int m = 0; m < C::EPL; m++) {
-        unsigned w = (unsigned)launder_ptr(c.P->aux.ai + c.P->aux.o_ent)[c.lane + WAVE * m];   // loaded here, in the rarely taken block
+        unsigned w = (unsigned)pt_global(launder_ptr(c.P->aux.ai + c.P->aux.o_ent))[c.lane + WAVE * m];   // loaded here, in the rarely taken block
         ent[m] = w & 0xFFFFu;
         pi[m] = (w >> 16) & 0xF; pj[m] = (w >> 20) & 0xF;
       }
@@ -1746,7 +1758,7 @@ __device__ __forceinline__ void forward(C& c) {
   } else {  // unknown tree shape: pack M into the Hessian buffer and use the dense factorisation
 #pragma unroll
     for (int m = 0; m < C::EPL; m++) {
-      unsigned e = (unsigned)launder_ptr(c.P->aux.ai + c.P->aux.o_ent)[c.lane + WAVE * m];   // (address arithmetic stays in this rarely taken block)
+      unsigned e = (unsigned)pt_global(launder_ptr(c.P->aux.ai + c.P->aux.o_ent))[c.lane + WAVE * m];   // (address arithmetic stays in this rarely taken block)
       e &= 0xFFFFu;
       if (e != 0xFFFFu) { int i = e >> 8, jj = e & 0xFF; S(H)[HP(i, jj)] = SAME_TREE(i, jj) ? S(M)[MIDX(i, jj)] : 0.0; }
     }
@@ -1915,15 +1927,17 @@ __device__ __forceinline__ void reset_state(C& c, uint64_t seed, uint32_t rc) {
 // L2 write-back / invalidate fence is needed per step: a release fence there flushes every dirty line of the XCD's L2,
 // scratch frames included, 2 million times a second (measured: 67 KB of HBM writes per env step against 2.5 KB algorithmic).
 // COH = false (per-step launch): plain accesses, the kernel boundary orders them.
+// (through global-address-space pointers: in the rollout kernel the buffers' addresses come out of the laundered launch arguments,
+// i.e. generic pointers, whose flat accesses would tie up the LDS counter as well -- see PT_GAS in ppo_tile.h)
 template <bool COH, class T>
 __device__ __forceinline__ T hand_load(const T* p) {
-  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *p;
+  if (COH) return __hip_atomic_load(pt_global(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *pt_global(p);
 }
 template <bool COH, class T>
 __device__ __forceinline__ void hand_store(T* p, T v) {
-  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
+  if (COH) __hip_atomic_store(pt_global(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *pt_global(p) = v;
 }
 
 template <bool COH = false, class C>
@@ -2001,8 +2015,8 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.tprev = clock64();
 #endif
 }
-template <bool COH = false, class C>
-__device__ __forceinline__ void load_state(C& c, const StepArgs& a, int e) {
+template <bool COH = false, class C, class SA>   // SA: StepArgs by value (per-step kernel) or in the kernel-argument segment (rollout kernel)
+__device__ __forceinline__ void load_state(C& c, const SA& a, int e) {
   const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
   const double* st = a.state + (size_t)e * a.state_stride;
   for (int i = lane; i < nq + 2 * nv; i += WAVE) {
@@ -2010,8 +2024,8 @@ __device__ __forceinline__ void load_state(C& c, const StepArgs& a, int e) {
     if (i < nq) S(qpos)[i] = v; else if (i < nq + nv) S(qvel)[i - nq] = v; else S(warm)[i - nq - nv] = v;
   }
 }
-template <bool COH = false, class C>
-__device__ __forceinline__ void store_state(C& c, const StepArgs& a, int e) {
+template <bool COH = false, class C, class SA>
+__device__ __forceinline__ void store_state(C& c, const SA& a, int e) {
   const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
   double* st = a.state + (size_t)e * a.state_stride;
   for (int i = lane; i < nq + 2 * nv; i += WAVE)
@@ -2069,14 +2083,14 @@ extern __shared__ double smem_dyn[];
 // observation write, state record back (the whole of SumoEnv._step + the wrappers + the worker's auto-reset:
 // sumo.py:120-202, sumo_env.py:40-72, monitor.py:51-78, subproc_vec_env.py:10-19).  Shared by the per-step launch
 // (sumo_step_kernel) and the fused multi-step rollout launch (sumo_rollout_kernel).
-template <bool COH = false, class C>
-__device__ __forceinline__ void env_step_body(C& c, const StepArgs& a, int e) {
+template <bool COH = false, class C, class SA>
+__device__ __forceinline__ void env_step_body(C& c, const SA& a, int e) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane;
   if (a.trace && lane == 0) a.trace[4 * e] = wall_clock64();
   load_state<COH>(c, a, e);
   if (!COH && lane < mdl.nu) {   // fused rollout: the policy phase has put the step's actions into S(ctrl) itself
-    const float* act0 = a.actions + (size_t)e * 2 * a.act_stride;
+    const float PT_GAS* act0 = pt_global(a.actions) + (size_t)e * 2 * a.act_stride;
     int ag = lane >= MI(agent_uadr)[1] ? 1 : 0;
     S(ctrl)[lane] = (double)act0[ag * a.act_stride + (lane - MI(agent_uadr)[ag])];
   }
@@ -2166,7 +2180,7 @@ __device__ __forceinline__ void env_step_body(C& c, const StepArgs& a, int e) {
   if (lane == 0) hand_store<COH>((uint16_t*)(a.done + 2 * e), (uint16_t)(dn ? 0x0101 : 0));
   if (lane == 0) { hand_store<COH>(a.ep_r + e, dn ? ep_ret : 0.0); hand_store<COH>(a.ep_dr + e, dn ? ep_dense : 0.0); hand_store<COH>(a.ep_l + e, dn ? num_steps : 0); }
   if (dn) {  // subproc_vec_env.py:13-16: auto-reset, reset observation replaces the terminal one
-    reset_state(c, a.seeds[e], (uint32_t)reset_count);
+    reset_state(c, pt_global(a.seeds)[e], (uint32_t)reset_count);
     reset_count++;
     num_steps = 0; ep_ret = 0; ep_dense = 0;
   }
@@ -2180,7 +2194,7 @@ __device__ __forceinline__ void env_step_body(C& c, const StepArgs& a, int e) {
   // work estimate for the next launch's longest-first schedule (sumo_step): Newton iterations dominate the variation
   // (a contention-independent proxy; sorting by the measured cycle count of the previous step schedules no better)
   // (least-squares fit of measured wave times, tools/slot_trace.py: Newton iterations, contacts, dense-path forwards)
-  if (lane == 0 && a.cost) { const int w = 1000 + 12 * c.st_newton + 10 * c.st_ncon + 60 * c.st_dense; a.cost[e] = w < 65535 ? w : 65535; }
+  if (lane == 0 && a.cost) { const int w = 1000 + 12 * c.st_newton + 10 * c.st_ncon + 60 * c.st_dense; pt_global(a.cost)[e] = w < 65535 ? w : 65535; }
   if (a.trace && lane == 0) {
     a.trace[4 * e + 1] = wall_clock64();
     a.trace[4 * e + 2] = (unsigned long long)c.st_newton | ((unsigned long long)c.st_ncon << 32);
@@ -2232,8 +2246,8 @@ struct RolloutArgs {
   float *st0, *st1;
 };
 
-template <class C>
-__device__ __forceinline__ void rollout_policy_phase(C& c, const StepArgs& a, const RolloutArgs& r, int e, int s) {
+template <class C, class SA, class RA>
+__device__ __forceinline__ void rollout_policy_phase(C& c, const SA& a, const RA& r, int e, int s) {
   const int lane = c.lane, i = lane & 15, kq = lane >> 4;
   const int D = r.L.D, A = r.L.A, XS = r.XS;
   float* xbuf = (float*)(c.sm + r.lds_off);        // [2][XS] | h1 [2][PT_HS] | h2 [2][PT_HS]
@@ -2246,17 +2260,17 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const StepArgs& a, co
   for (int k = lane; k < D; k += WAVE) {
     const float o0 = hand_load<true>(ob + k), o1 = hand_load<true>(ob + a.obs_stride + k);
     xbuf[k] = o0; xbuf[XS + k] = o1;
-    r.obs[slot0 * D + k] = o0; r.obs[slot1 * D + k] = o1;
+    pt_global(r.obs)[slot0 * D + k] = o0; pt_global(r.obs)[slot1 * D + k] = o1;
   }
-  if (lane < 2) r.done[lane == 0 ? slot0 : slot1] = (uint8_t)(hand_load<true>((const uint16_t*)(a.done + 2 * e)) >> (8 * lane));
+  if (lane < 2) pt_global(r.done)[lane == 0 ? slot0 : slot1] = (uint8_t)(hand_load<true>((const uint16_t*)(a.done + 2 * e)) >> (8 * lane));
   wave_sync();
-  const float* lp = r.learner;
-  const float* op = r.opponent + (size_t)(r.opp_idx ? r.opp_idx[e] : 0) * r.L.P;
-  const f32x4 mL = trunk_forward<false, 2>(pi_net(lp, r.L), xbuf, XS, D, h1, h2, lane);
+  const float PT_GAS* lp = pt_global(r.learner);
+  const float PT_GAS* op = pt_global(r.opponent) + (size_t)(r.opp_idx ? pt_global(r.opp_idx)[e] : 0) * r.L.P;
+  const f32x4 mL = trunk_forward<false, 2>(pi_net((const float*)lp, r.L), xbuf, XS, D, h1, h2, lane);
   wave_sync();
-  const f32x4 mO = trunk_forward<false, 2>(pi_net(op, r.L), xbuf, XS, D, h1, h2, lane);
+  const f32x4 mO = trunk_forward<false, 2>(pi_net((const float*)op, r.L), xbuf, XS, D, h1, h2, lane);
   wave_sync();
-  const f32x4 vL = trunk_forward<false, 2>(vf_net(lp, r.L), xbuf, XS, D, h1, h2, lane);
+  const f32x4 vL = trunk_forward<false, 2>(vf_net((const float*)lp, r.L), xbuf, XS, D, h1, h2, lane);
   // heads: row 0 = agent 0 (learner acts, opponent scores), row 1 = agent 1 (opponent acts, learner scores and values)
   const bool colk = i < A;
   const float lsL = colk ? lp[r.L.logstd + i] : 0.0f, lsO = colk ? op[r.L.logstd + i] : 0.0f;
@@ -2264,22 +2278,22 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const StepArgs& a, co
   const float sumL = row16_sum(lsL), sumO = row16_sum(lsO);
   const bool ok = colk && kq == 0;                  // rows 0 and 1 live in the first 16 lanes (D layout: rows 4 kq + r)
   const size_t nz = ((size_t)s * a.N + e) * A + i;
-  const float n0 = ok ? r.noise0[nz] : 0.0f, n1 = ok ? r.noise1[nz] : 0.0f;
+  const float n0 = ok ? pt_global(r.noise0)[nz] : 0.0f, n1 = ok ? pt_global(r.noise1)[nz] : 0.0f;
   float act0 = 0.0f, act1 = 0.0f;
   const float nlp0 = gauss_row(mL[0], stdL, sumL, ok, true, n0, act0, A);      // learner samples for agent 0 ...
   const float onlp0 = gauss_row(mO[0], stdO, sumO, ok, false, 0.0f, act0, A);  // ... the opponent net scores that action
   const float onlp1 = gauss_row(mO[1], stdO, sumO, ok, true, n1, act1, A);     // opponent samples for agent 1 ...
   const float nlp1 = gauss_row(mL[1], stdL, sumL, ok, false, 0.0f, act1, A);   // ... the learner scores it
   if (ok) {
-    r.act[slot0 * A + i] = act0; r.act[slot1 * A + i] = act1;
+    pt_global(r.act)[slot0 * A + i] = act0; pt_global(r.act)[slot1 * A + i] = act1;
     float* ae = const_cast<float*>(a.actions) + (size_t)e * 2 * a.act_stride;
     hand_store<true>(ae + i, act0); hand_store<true>(ae + a.act_stride + i, act1);     // the env's action buffer (output only)
     const sumo_model_t& mdl = c.P->mdl;
     S(ctrl)[MI(agent_uadr)[0] + i] = (double)act0; S(ctrl)[MI(agent_uadr)[1] + i] = (double)act1;   // the step's control vector
   }
   if (lane == 0) {
-    r.nlp[slot0] = nlp0; r.nlp[slot1] = nlp1; r.onlp[slot0] = onlp0; r.onlp[slot1] = onlp1;
-    r.val[slot0] = vL[0]; r.val[slot1] = vL[1];
+    pt_global(r.nlp)[slot0] = nlp0; pt_global(r.nlp)[slot1] = nlp1; pt_global(r.onlp)[slot0] = onlp0; pt_global(r.onlp)[slot1] = onlp1;
+    pt_global(r.val)[slot0] = vL[0]; pt_global(r.val)[slot1] = vL[1];
   }
   wave_sync();   // the action buffer is read back by the env step (other lanes), the scratch region becomes the mass matrix again
 }
@@ -2294,10 +2308,10 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const StepArgs& a, co
 // Gate pre-activations run on the vector ALU in the MFMA tiles' accumulation order (lstm_gates_valu), cell update and heads
 // through the functions ppo_lstm_step_kernel uses: every number equals the launch-per-evaluation path bit for bit.
 // LDS (floats, from lds_off): x [2][XS] | zero row [NH] | previous latents [3][NH] | new latents [3][NH].
-template <int NH, class C>
-__device__ __forceinline__ void rollout_policy_phase_lstm(C& c, const StepArgs& a, const RolloutArgs& r, int e, int s) {
+template <int NH, class C, class SA, class RA>
+__device__ __forceinline__ void rollout_policy_phase_lstm(C& c, const SA& a, const RA& r, int e, int s) {
   const int lane = c.lane;
-  const ppo_lstm_net& NL = r.lnet;
+  const auto& NL = r.lnet;
   const int D = NL.ob_dim, A = NL.ac_dim, XS = r.XS;
   float* xo = (float*)(c.sm + r.lds_off);
   float* hz = xo + 2 * XS;
@@ -2310,12 +2324,12 @@ __device__ __forceinline__ void rollout_policy_phase_lstm(C& c, const StepArgs& 
     float o0 = 0.0f, o1 = 0.0f;
     if (k < D) {
       o0 = hand_load<true>(ob + k); o1 = hand_load<true>(ob + a.obs_stride + k);
-      r.obs[slot0 * D + k] = o0; r.obs[slot1 * D + k] = o1;
+      pt_global(r.obs)[slot0 * D + k] = o0; pt_global(r.obs)[slot1 * D + k] = o1;
     }
     xo[k] = o0; xo[XS + k] = o1;
   }
   const unsigned dn = hand_load<true>((const uint16_t*)(a.done + 2 * e));   // done flags of the previous step = the masks M
-  if (lane < 2) r.done[lane == 0 ? slot0 : slot1] = (uint8_t)(dn >> (8 * lane));
+  if (lane < 2) pt_global(r.done)[lane == 0 ? slot0 : slot1] = (uint8_t)(dn >> (8 * lane));
   const float keep0 = 1.0f - (float)(dn & 0xff), keep1 = 1.0f - (float)((dn >> 8) & 0xff);
   // the acting nets' states: lane owns the units 2 lane, 2 lane + 1
   float* s0p = r.st0 + (size_t)e * 2 * NH;
@@ -2331,21 +2345,24 @@ __device__ __forceinline__ void rollout_policy_phase_lstm(C& c, const StepArgs& 
     hz[j0] = 0.0f; hz[j0 + 1] = 0.0f;
   }
   wave_sync();
-  const ppo_lstm_net* NOp = r.onets + (r.tile_net ? r.tile_net[col >> 4] : 0);
+  const ppo_lstm_net PT_GAS* NOp = pt_global(r.onets) + (r.tile_net ? pt_global(r.tile_net)[col >> 4] : 0);
   const bool ok = lane < A;
   const size_t nz = ((size_t)s * a.N + e) * A + lane;
   float act0 = 0.0f, act1 = 0.0f, onlp1, mOB, stdO, sumO;
   {  // ---- opponent net: rows A, B
-    const float *owx = NOp->wx, *owh = NOp->wh, *ob_ = NOp->b;
+    const float *owx = NOp->wx, *owh = NOp->wh;
+    const float PT_GAS* ob_ = pt_global(NOp->b);
     const float fb = NOp->forget_bias;
-    float z[4][2][2];
+    float z[4][2][2], bz[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; g++) { bz[g][0] = ob_[g * NH + j0]; bz[g][1] = ob_[g * NH + j0 + 1]; }   // (in flight during the gate sums)
     const float* const xr[2] = {xo + XS, xo};
     const float* const hr[2] = {hp, hz};
     lstm_gates_valu<NH, 2>(owx, owh, D, xr, hr, lane, z);
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int j = j0 + u;
-      const float bi = ob_[j], bf = ob_[NH + j] + fb, bo = ob_[2 * NH + j], bu = ob_[3 * NH + j];   // gate order i, f, o, u
+      const float bi = bz[0][u], bf = bz[1][u] + fb, bo = bz[2][u], bu = bz[3][u];   // gate order i, f, o, u
       const LstmCell ca = lstm_cell(z[0][u][0], z[1][u][0], z[2][u][0], z[3][u][0], bi, bf, bo, bu, c1[u]);
       const LstmCell cb = lstm_cell(z[0][u][1], z[1][u][1], z[2][u][1], z[3][u][1], bi, bf, bo, bu, hz[j]);
       hand_store<true>(s1p + j, ca.cn); hand_store<true>(s1p + NH + j, ca.hn);      // agent 1's state after the opponent's step
@@ -2355,24 +2372,26 @@ __device__ __forceinline__ void rollout_policy_phase_lstm(C& c, const StepArgs& 
     wave_sync();
     float m[2];
     lstm_heads_valu<NH, 2>(NOp->head_w, NOp->vf_w, A, hn, lane, m);
-    const float hb = ok ? NOp->head_b[lane] : 0.0f, ls = ok ? NOp->logstd[lane] : 0.0f;
+    const float hb = ok ? pt_global(NOp->head_b)[lane] : 0.0f, ls = ok ? pt_global(NOp->logstd)[lane] : 0.0f;
     stdO = expf(ls); sumO = row16_sum(ls);
     mOB = m[1] + hb;
-    const float n1 = ok ? r.noise1[nz] : 0.0f;
+    const float n1 = ok ? pt_global(r.noise1)[nz] : 0.0f;
     onlp1 = gauss_row(m[0] + hb, stdO, sumO, ok, true, n1, act1, A);     // the opponent samples for agent 1
     wave_sync();   // the latent rows are rewritten by the learner's pass
   }
   float nlp0, nlp1, onlp0, v0, v1;
   {  // ---- learner net: rows C, D, E
     const float fb = NL.forget_bias;
-    float z[4][2][3];
+    float z[4][2][3], bz[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; g++) { bz[g][0] = pt_global(NL.b)[g * NH + j0]; bz[g][1] = pt_global(NL.b)[g * NH + j0 + 1]; }
     const float* const xr[3] = {xo, xo + XS, xo + XS};
     const float* const hr[3] = {hp + NH, hp + 2 * NH, hz};
     lstm_gates_valu<NH, 3>(NL.wx, NL.wh, D, xr, hr, lane, z);
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int j = j0 + u;
-      const float bi = NL.b[j], bf = NL.b[NH + j] + fb, bo = NL.b[2 * NH + j], bu = NL.b[3 * NH + j];
+      const float bi = bz[0][u], bf = bz[1][u] + fb, bo = bz[2][u], bu = bz[3][u];
       const LstmCell cc = lstm_cell(z[0][u][0], z[1][u][0], z[2][u][0], z[3][u][0], bi, bf, bo, bu, c0[u]);
       const LstmCell cd = lstm_cell(z[0][u][1], z[1][u][1], z[2][u][1], z[3][u][1], bi, bf, bo, bu, cD[u]);
       const LstmCell ce = lstm_cell(z[0][u][2], z[1][u][2], z[2][u][2], z[3][u][2], bi, bf, bo, bu, hz[j]);
@@ -2382,41 +2401,41 @@ __device__ __forceinline__ void rollout_policy_phase_lstm(C& c, const StepArgs& 
     wave_sync();
     float m[3];
     lstm_heads_valu<NH, 3>(NL.head_w, NL.vf_w, A, hn, lane, m);
-    const float hb = ok ? NL.head_b[lane] : 0.0f, ls = ok ? NL.logstd[lane] : 0.0f;
+    const float hb = ok ? pt_global(NL.head_b)[lane] : 0.0f, ls = ok ? pt_global(NL.logstd)[lane] : 0.0f;
     const float stdL = expf(ls), sumL = row16_sum(ls);
-    const float vb = NL.vf_b[0];
+    const float vb = pt_global(NL.vf_b)[0];
     v0 = __shfl(m[0], 16) + vb; v1 = __shfl(m[1], 16) + vb;
-    const float n0 = ok ? r.noise0[nz] : 0.0f;
+    const float n0 = ok ? pt_global(r.noise0)[nz] : 0.0f;
     nlp0 = gauss_row(m[0] + hb, stdL, sumL, ok, true, n0, act0, A);      // the learner samples for agent 0 ...
     onlp0 = gauss_row(mOB, stdO, sumO, ok, false, 0.0f, act0, A);        // ... the opponent net (zero state) scores that action
     nlp1 = gauss_row(m[2] + hb, stdL, sumL, ok, false, 0.0f, act1, A);   // the learner (zero state) scores the opponent's action
   }
   if (ok) {
-    r.act[slot0 * A + lane] = act0; r.act[slot1 * A + lane] = act1;
+    pt_global(r.act)[slot0 * A + lane] = act0; pt_global(r.act)[slot1 * A + lane] = act1;
     float* ae = const_cast<float*>(a.actions) + (size_t)e * 2 * a.act_stride;
     hand_store<true>(ae + lane, act0); hand_store<true>(ae + a.act_stride + lane, act1);
     const sumo_model_t& mdl = c.P->mdl;
     S(ctrl)[MI(agent_uadr)[0] + lane] = (double)act0; S(ctrl)[MI(agent_uadr)[1] + lane] = (double)act1;
   }
   if (lane == 0) {
-    r.nlp[slot0] = nlp0; r.nlp[slot1] = nlp1; r.onlp[slot0] = onlp0; r.onlp[slot1] = onlp1;
-    r.val[slot0] = v0; r.val[slot1] = v1;
+    pt_global(r.nlp)[slot0] = nlp0; pt_global(r.nlp)[slot1] = nlp1; pt_global(r.onlp)[slot0] = onlp0; pt_global(r.onlp)[slot1] = onlp1;
+    pt_global(r.val)[slot0] = v0; pt_global(r.val)[slot1] = v1;
   }
   wave_sync();
 }
 
-template <class C>
-__device__ __forceinline__ void rollout_post_phase(C& c, const StepArgs& a, const RolloutArgs& r, int e, int s) {
+template <class C, class SA, class RA>
+__device__ __forceinline__ void rollout_post_phase(C& c, const SA& a, const RA& r, int e, int s) {
   SYNC();   // the step's reward inputs and episode record were parked in LDS by lane 0 of the epilogue
   const int lane = c.lane;
   const size_t col = (size_t)r.env_offset + e;
   if (lane < 2) {   // runner.py:134 + monitor.py:63-78 harvest, as ppo_post_step_kernel
     const double* sh = S(stash) + 5;
-    r.rew[((size_t)lane * r.T + s) * r.Ntot + col] = reward_mix(r.alpha, sh[2 * lane], sh[2 * lane + 1]);
+    pt_global(r.rew)[((size_t)lane * r.T + s) * r.Ntot + col] = reward_mix(r.alpha, sh[2 * lane], sh[2 * lane + 1]);
     if (lane == 0) {
       const size_t t = (size_t)s * r.Ntot + col;
       const int* rec = (const int*)(sh + 5);
-      r.ep_done[t] = (uint8_t)rec[1]; r.ep_r[t] = sh[4]; r.ep_l[t] = rec[0];
+      pt_global(r.ep_done)[t] = (uint8_t)rec[1]; pt_global(r.ep_r)[t] = sh[4]; pt_global(r.ep_l)[t] = rec[0];
     }
   }
 }
@@ -2446,11 +2465,12 @@ sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
   // `launch_args` is read in place from the kernel-argument segment (second argument, 8-byte aligned right behind P) through a
   // pointer the loop launders per ticket -- see the note above RolloutLaunch
   (void)launch_args;
-  const RolloutLaunch* LP = (const RolloutLaunch*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(const Params*));
+  typedef const RolloutLaunch PT_CAS* LaunchPtr;   // constant address space: every field read is a scalar load
+  const LaunchPtr LP = (LaunchPtr)((const char PT_CAS*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(const Params*));
   Ctx<NV> c;
   ctx_init(c, P, smem_dyn);
   for (;;) {
-    const RolloutLaunch* lp = launder_sptr(LP);
+    LaunchPtr lp = launder_sptr(LP);
     int* sched = lp->r.sched;                      // [0] ticket counter, [1] abort flag, [2 + e] finished steps of env e
     const int N = lp->a.N;
     int t = 0;

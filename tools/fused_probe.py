@@ -13,19 +13,32 @@ ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--env-id", default="RoboSumo-Ant-vs-Ant-v0")
 ap.add_argument("--configs", default="2:0:0,1:1:0,1:1:0")
+ap.add_argument("--lstm", type=int, default=0, help="recurrent policies (LSTM(128)); value = opponent pool size (1 = a single opponent model)")
 a = ap.parse_args()
 for cfg in a.configs.split(","):
     groups, fused, chunk = (int(x) for x in cfg.split(":"))
     env = SumoVecEnv(a.env_id, num_envs=a.envs, seed=1000, groups=groups)
     spec = policies.PolicySpec(env.observation_space[0].shape[0], env.action_space[0].shape[0], value_network="copy", activation="relu")
-    ms = [model_mod.PPOModel(policy=spec, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, trainable=False) for _ in range(2)]
+    if a.lstm:
+        from robosumo_selfplay_amd import lstm_model
+        from robosumo_selfplay_amd.opponent_pool import LstmOpponentPool
+        lspec = lstm_model.LstmSpec(spec.ob_dim, spec.ac_dim, 128)
+        ms = [lstm_model.LstmPPOModel(policy=lspec, nbatch_act=a.envs, nsteps=a.steps, trainable=False) for _ in range(2)]
+        if a.lstm > 1:
+            pool = LstmOpponentPool(lspec, a.lstm, a.envs, env.device)
+            for k in range(a.lstm):
+                pool.set_snapshot(k, ms[1].get_param_list())
+            pool.assign_round_robin()
+            ms[1] = pool
+    else:
+        ms = [model_mod.PPOModel(policy=spec, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, trainable=False) for _ in range(2)]
     r = Runner(env=env, models=ms, nsteps=a.steps, nagent=2, gamma=0.995, lam=0.95, rho_bar=1.0, c_bar=1.0)
     B = r._alloc_device(a.steps)
     def run():
         if fused:
             c = chunk or a.steps
             for s0 in range(0, a.steps, c):
-                r._steps_fused(B, s0, min(c, a.steps - s0), 1.0)
+                (r._steps_fused_lstm if a.lstm else r._steps_fused)(B, s0, min(c, a.steps - s0), 1.0)
         else:
             for s in range(a.steps):
                 r._step_device(B, s, 1.0)
