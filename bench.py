@@ -157,6 +157,48 @@ def spider_segment(torch, dev, local_rank, args, hp):
     return out
 
 
+def recurrent_segment(torch, dev, local_rank, args, hp):
+    """Secondary driver-timed line (BASELINE config 5's one-GPU shard): Ant-vs-Ant, 1024 envs, LSTM(128) policies against a pool of 16
+    frozen snapshots (one per 16-env tile), the whole recurrent rollout step in the fused launch (sumo_rollout_steps_lstm)."""
+    from robosumo_selfplay_amd import lstm_model, mjcf
+    from robosumo_selfplay_amd.opponent_pool import LstmOpponentPool
+    from robosumo_selfplay_amd.runner import Runner
+    from robosumo_selfplay_amd.vec_env import SumoVecEnv
+    env_id, N, K, P = "RoboSumo-Ant-vs-Ant-v0", 1024, args.recurrent_steps, 16
+    env = SumoVecEnv(env_id, num_envs=N, seed=78, device=local_rank, model=mjcf.load_model(env_id), groups=1)
+    spec = lstm_model.LstmSpec(env.observation_space[0].shape[0], env.action_space[0].shape[0], 128)
+    learner = lstm_model.LstmPPOModel(policy=spec, nbatch_act=N, nsteps=K, trainable=False, device=local_rank)
+    pool = LstmOpponentPool(spec, P, N, env.device)
+    for k in range(P):
+        pool.set_snapshot(k, learner.get_param_list())
+    pool.assign_round_robin()
+    r = Runner(env=env, models=[learner, pool], nsteps=K, nagent=2, gamma=hp["gamma"], lam=hp["lam"], rho_bar=hp["rho_bar"], c_bar=hp["c_bar"])
+    r.fused_rollout = not args.stepwise
+    fused = r.fused_lstm_ok()
+    B = r._alloc_device(K)
+
+    def advance(n):
+        for s0 in range(0, n, K):
+            if fused:
+                r._steps_fused_lstm(B, 0, min(K, n - s0), 1.0)
+            else:
+                for k in range(min(K, n - s0)):
+                    r._step_device(B, k, 1.0)
+    advance(args.state_warmup)
+    r.join_groups()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    advance(K)
+    r.join_groups()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    out = {"env_id": env_id, "envs": N, "steps": K, "policy": "lstm(128), shared value head", "opponent_pool": P,
+           "env_steps_per_s": N * K / dt, "ms_per_step": dt / K * 1e3, "rollout_path": "fused" if fused else "stepwise",
+           "note": "1024 envs leave half of the chip's 2048 wave slots empty: the launch lasts as long as its slowest env's chain of steps"}
+    env.close()
+    return out
+
+
 def cpu_baseline(model, states, actions, steps, threads):
     """Times the CPU oracle (the float64 restatement; the reference's MuJoCo path cannot run here) on a bounded
     sample of the same workload: the first len(states[0]) envs of the GPU batch, same states, same action law."""
@@ -192,6 +234,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the cgroup CPU quota of this job (hostcfg.cpu_quota)")
     ap.add_argument("--no-mfma-probe", action="store_true")
     ap.add_argument("--spider-steps", type=int, default=30, help="timed rollout steps of the secondary Spider-vs-Spider 4096-env line (0 = skip)")
+    ap.add_argument("--recurrent-steps", type=int, default=64, help="timed rollout steps of the secondary recurrent line (config-5 shard: 1024 envs, LSTM(128), pool of 16; 0 = skip)")
     ap.add_argument("--state-warmup", type=int, default=100,
                     help="untimed rollout steps that bring the env states from the reset law to the steady workload (SURVEY.md 8(d): >= 100)")
     args = ap.parse_args()
@@ -352,6 +395,9 @@ def main():
     spider = None
     if args.spider_steps > 0 and rank == 0 and "Ant-vs-Ant" in args.env_id:
         spider = spider_segment(torch, dev, local_rank, args, hp)
+    recurrent = None
+    if args.recurrent_steps > 0 and rank == 0 and "Ant-vs-Ant" in args.env_id:
+        recurrent = recurrent_segment(torch, dev, local_rank, args, hp)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -374,13 +420,13 @@ def main():
             except Exception:
                 return None
         traffic, traffic_src = None, None
-        for cand in ("r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01f_pmc_traffic.json"):
+        for cand in ("r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01f_pmc_traffic.json"):
             pj = profile_json(cand)
             if pj is not None:          # per env step in the profile, scaled to this launch's env steps
                 traffic, traffic_src = pj["traffic_bytes_per_env_step"] * steps_per_launch, "profiles/" + cand
                 break
         sq, sq_src = None, None
-        for cand in ("r02b_pmc_sq.json", "r02_pmc_sq.json"):
+        for cand in ("r02c_pmc_sq.json", "r02b_pmc_sq.json", "r02_pmc_sq.json"):
             sq = profile_json(cand)
             if sq is not None:
                 sq_src = "profiles/" + cand
@@ -426,6 +472,8 @@ def main():
             out["roofline_mfma"] = dict(mfma, bound="mfma", peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", dtype="f32 (v_mfma_f32_16x16x4_f32)")
         if spider is not None:
             out["config"]["spider"] = spider
+        if recurrent is not None:
+            out["config"]["recurrent"] = recurrent
         out["host"] = {"cpu_model": hostcfg.cpu_model(), "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": hostcfg.cpu_quota(),
                        "pool_threads": hostcfg.apply(),
                        "throttled_periods_in_timed_region": None if thr0 is None or thr1 is None else thr1[0] - thr0[0]}

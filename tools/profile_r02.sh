@@ -8,8 +8,8 @@ TAG=${1:-r02b}
 K=20
 O=gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
-B="python3 bench.py --steps $K --warmup $K --state-warmup 100 --no-cpu-baseline --ppo-nsteps 0 --spider-steps 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --spider-steps 0 > $O/stats.log 2>&1 || exit 11
+B="python3 bench.py --steps $K --warmup $K --state-warmup 100 --no-cpu-baseline --ppo-nsteps 0 --spider-steps 0 --recurrent-steps 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --spider-steps 0 --recurrent-steps 32 > $O/stats.log 2>&1 || exit 11
 echo stats done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o $TAG -- $B > $O/sq.log 2>&1 || exit 12
 echo sq done
