@@ -96,6 +96,15 @@ int ppo_lstm_step_pool(const ppo_lstm_net* proto, const ppo_lstm_net* nets_dev, 
  *   previous state, save_tanhc [n][hidden] tanh of the new cell state (the new h is the latent: read it from `h`). */
 int ppo_lstm_step_save(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
                        int state_stride, float* save_gates, float* save_cprev, float* save_hprev, float* save_tanhc, void* stream);
+/* The unrolled forward with the input block hoisted out of the recurrence: ppo_lstm_xproj computes z_out [rows][4*hidden] = x * wx
+ * for all rows = (time, env) pairs of a minibatch in one launch (same tiles and k order as the step kernel's input block);
+ * ppo_lstm_step_save_z is ppo_lstm_step_save for one time step whose gate sums start from z_t [n][4*hidden] (that step's rows of
+ * z_out) instead of from the observations -- bit-identical to ppo_lstm_step_save on the same inputs, with half the dependent
+ * chain per step -- and also writes the new latent to latent_out [n][hidden] (NULL = skip).  Nets without embedding /
+ * observation filter only (what learn(network='lstm') trains). */
+int ppo_lstm_xproj(const ppo_lstm_net* net, const float* obs, int rows, int obs_stride, float* z_out, void* stream);
+int ppo_lstm_step_save_z(const ppo_lstm_net* net, const float* z_t, int n, const float* mask, float* c, float* h, int state_stride,
+                         float* save_gates, float* save_cprev, float* save_hprev, float* save_tanhc, float* latent_out, void* stream);
 /* PPO loss heads on stored latents (rows = all (time, env) pairs of the minibatch): forward of the Gaussian / value heads,
  * loss terms of model.py:65-111 and their gradients.  Outputs: dlatent [rows][hidden], dmean [rows][ac_dim], dvalue [rows],
  * dlogstd_rows [rows][ac_dim] (sum over rows - ent_coef = d loss / d logstd), stats double[PPO_NSTATS] (+= un-normalised sums

@@ -287,10 +287,12 @@ struct LstmArgs {
   const float *obs, *mask, *noise, *given;
   float *c, *h, *action, *neglogp, *value, *mean;
   float *sv_gates, *sv_cprev, *sv_hprev, *sv_tanhc;   // training: per-step records for the backward pass (all or none)
+  const float* zinit;         // training: x * wx of this time step [n][4 NH] from ppo_lstm_xproj (the gate tiles start from it; no obs)
+  float* sv_latent;           // training: the new latent [n][NH] (a copy of the h rows, in the layout the head / weight gradients read)
   int n, obs_stride, state_stride, XS, HP;
 };
 
-template <int NH, int ORDER>   // hidden units: 64 or 128; gate order (static so the gate tiles are static registers)
+template <int NH, int ORDER, bool ZIN = false>   // hidden units: 64 or 128; gate order (static so the gate tiles are static registers); ZIN: gate sums start from LstmArgs::zinit
 __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
   // FOUR waves per 16-row tile: wave w owns the units [w NH/4, (w+1) NH/4) -- all four gates of those units, their cell
   // update and their slice of the new latent -- so the serial chain per wave is a quarter of the tile's (one wave per tile
@@ -303,7 +305,25 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
   float* hprev = ebuf + 16 * HS;
   float* hnew = hprev + 16 * HP;
   const int i = lane & 15, kq = lane >> 4;
-  stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, tid, N.obs_mean, N.obs_invstd, N.obs_clip, 256);
+  constexpr int UT = NH / 16, UTW = UT / 4, NTW = 4 * UTW;   // unit tiles, unit tiles per wave, gate tiles per wave
+  f32x4 z[NTW];
+  if (ZIN) {   // (first thing in the kernel: these loads are in flight while the previous latent is staged)
+    // the input block's partial sums come from ppo_lstm_xproj (same k order from zero): continuing the accumulation on them with
+    // the recurrent block gives the very sums of the full loop, with half the dependent chain
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int u = 0; u < UTW; u++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = r0 + 4 * kq + r;
+          z[g * UTW + u][r] = row < a.n ? a.zinit[(size_t)row * 4 * NH + (g * UT + wid * UTW + u) * 16 + i] : 0.0f;
+        }
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < NTW; ct++) z[ct] = (f32x4){0, 0, 0, 0};
+  }
+  if (!ZIN) stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, tid, N.obs_mean, N.obs_invstd, N.obs_clip, 256);
   // h_prev * (1 - mask): eight state loads in flight per thread
   for (int e0 = 0; e0 < 16 * NH; e0 += 8 * 256) {
     float v[8], keep[8];
@@ -327,7 +347,7 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
   __syncthreads();
   // ---- optional embedding: relu(x * We + be), 64 wide (wave 0)
   const float* xin = xbuf; int xk = D, xs = XS;
-  if (N.emb_w) {
+  if (N.emb_w && !ZIN) {
     if (wid == 0) {
       f32x4 acc[4];
 #pragma unroll
@@ -351,14 +371,10 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
     xin = ebuf; xk = E; xs = HS;
   }
   // ---- gates z = x * wx + h_prev * wh + b for this wave's units: tiles (gate g, unit tile wid*UTW + u)
-  constexpr int UT = NH / 16, UTW = UT / 4, NTW = 4 * UTW;   // unit tiles, unit tiles per wave, gate tiles per wave
-  f32x4 z[NTW];
-#pragma unroll
-  for (int ct = 0; ct < NTW; ct++) z[ct] = (f32x4){0, 0, 0, 0};
   {
     // k-steps run over the input block (wx) and then the recurrent block (wh); the weight operands of step s+1 are
     // loaded before the products of step s are issued (two register sets); accumulation order per tile as ever
-    const int xsteps = (xk + 3) >> 2, nsteps = xsteps + NH / 4;
+    const int xsteps = ZIN ? 0 : (xk + 3) >> 2, nsteps = xsteps + NH / 4;
     auto fetch = [&](int s_, float& av, float (&b)[NTW]) {
       if (s_ < xsteps) {
         const int k = 4 * s_ + kq;
@@ -415,6 +431,7 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
           sg[gi * NH + j] = ig; sg[gf * NH + j] = fg; sg[go * NH + j] = og; sg[gu * NH + j] = ug;
           a.sv_cprev[(size_t)row * NH + j] = cp; a.sv_tanhc[(size_t)row * NH + j] = tcn;
         }
+        if (a.sv_latent) a.sv_latent[(size_t)row * NH + j] = hn;
       }
       hnew[(4 * kq + r) * HP + j] = hn;
     }
@@ -465,11 +482,62 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
   }
 }
 
+// x * wx for ALL time steps of a training minibatch at once (rows = time x env): the input block of the gate sums does not
+// depend on the recurrence, so it leaves the sequential part of the unrolled forward (the classic split of an LSTM forward into
+// one large input GEMM and T small recurrent steps).  Same tiles, same k order from zero as ppo_lstm_step_kernel's input block:
+// the step kernel continues the accumulation on these partial sums (LstmArgs::zinit) and reproduces its own full loop bit for bit.
+template <int NH>
+__global__ void __launch_bounds__(256) ppo_lstm_xproj_kernel(ppo_lstm_net N, const float* obs, int rows, int obs_stride, float* zout, int XS) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r0 = blockIdx.x * 16;
+  const int D = N.ob_dim, i = lane & 15, kq = lane >> 4;
+  float* xbuf = smem_f;
+  stage_x(xbuf, XS, obs, obs_stride, D, nullptr, r0, rows, tid, N.obs_mean, N.obs_invstd, N.obs_clip, 256);
+  __syncthreads();
+  constexpr int UT = NH / 16, UTW = UT / 4, NTW = 4 * UTW;
+  f32x4 z[NTW];
+#pragma unroll
+  for (int ct = 0; ct < NTW; ct++) z[ct] = (f32x4){0, 0, 0, 0};
+  const int xsteps = (D + 3) >> 2;
+  auto fetch = [&](int s_, float& av, float (&b)[NTW]) {
+    const int k = 4 * s_ + kq;
+    const bool ok = k < D;
+    av = ok ? xbuf[i * XS + k] : 0.0f;
+    const float* wrow = N.wx + (size_t)(ok ? k : 0) * 4 * NH;
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int u = 0; u < UTW; u++) b[g * UTW + u] = ok ? wrow[(g * UT + wid * UTW + u) * 16 + i] : 0.0f;
+  };
+  float a0 = 0.0f, a1 = 0.0f, b0[NTW], b1[NTW];
+  fetch(0, a0, b0);
+  for (int s_ = 0; s_ < xsteps; s_ += 2) {
+    if (s_ + 1 < xsteps) fetch(s_ + 1, a1, b1);
+#pragma unroll
+    for (int ct = 0; ct < NTW; ct++) z[ct] = MFMA(a0, b0[ct], z[ct]);
+    if (s_ + 2 < xsteps) fetch(s_ + 2, a0, b0);
+    if (s_ + 1 < xsteps) {
+#pragma unroll
+      for (int ct = 0; ct < NTW; ct++) z[ct] = MFMA(a1, b1[ct], z[ct]);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int u = 0; u < UTW; u++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = r0 + 4 * kq + r;
+        if (row < rows) zout[(size_t)row * 4 * NH + (g * UT + wid * UTW + u) * 16 + i] = z[g * UTW + u][r];
+      }
+}
+
 static int lstm_launch(const ppo_lstm_net* net, const float* obs, int n, int obs_stride, const float* mask, float* c, float* h,
                        int state_stride, const float* noise, const float* given_action, float* action_out, float* neglogp_out,
                        float* value_out, float* mean_out, float* sv_gates, float* sv_cprev, float* sv_hprev, float* sv_tanhc,
-                       void* stream, const ppo_lstm_net* pool_dev = nullptr, const int32_t* tile_net_dev = nullptr) {
-  if (!net || !obs || !c || !h || n <= 0) FAIL(-1, "bad arguments");
+                       void* stream, const ppo_lstm_net* pool_dev = nullptr, const int32_t* tile_net_dev = nullptr,
+                       const float* zinit = nullptr, float* sv_latent = nullptr) {
+  if (!net || (!obs && !zinit) || !c || !h || n <= 0) FAIL(-1, "bad arguments");
+  if (zinit && (net->emb_w || net->obs_mean)) FAIL(-10, "precomputed input sums: nets without embedding / observation filter only");
   if (net->hidden != 64 && net->hidden != 128) FAIL(-2, "hidden %d: only 64 and 128 are built", net->hidden);
   if (net->ob_dim < 1 || net->ob_dim > 512 || obs_stride < net->ob_dim) FAIL(-3, "bad ob_dim/obs_stride");
   if (net->emb_w && (net->emb_dim < 1 || net->emb_dim > 64 || !net->emb_b)) FAIL(-4, "embedding width %d not in [1,64]", net->emb_dim);
@@ -482,6 +550,7 @@ static int lstm_launch(const ppo_lstm_net* net, const float* obs, int n, int obs
   a.net = *net; a.obs = obs; a.mask = mask; a.noise = noise; a.given = given_action; a.c = c; a.h = h; a.action = action_out;
   a.neglogp = neglogp_out; a.value = value_out; a.mean = mean_out; a.n = n; a.obs_stride = obs_stride; a.state_stride = state_stride;
   a.sv_gates = sv_gates; a.sv_cprev = sv_cprev; a.sv_hprev = sv_hprev; a.sv_tanhc = sv_tanhc;
+  a.zinit = zinit; a.sv_latent = sv_latent;
   a.XS = x_stride(net->ob_dim); a.HP = net->hidden + 2;
   size_t lds = (size_t)(16 * a.XS + 16 * HS + 2 * 16 * a.HP) * sizeof(float);
   int tiles = (n + 15) / 16;
@@ -489,6 +558,12 @@ static int lstm_launch(const ppo_lstm_net* net, const float* obs, int n, int obs
   const bool ifou = net->gate_order == PPO_LSTM_GATES_IFOU;
   dim3 g(tiles), b(256);
   hipStream_t st = (hipStream_t)stream;
+  if (zinit) {   // training forward on precomputed input sums
+    if (net->hidden == 64 && ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IFOU, true>), g, b, lds, st, a);
+    else if (net->hidden == 64) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IJFO, true>), g, b, lds, st, a);
+    else if (ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IFOU, true>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IJFO, true>), g, b, lds, st, a);
+  } else
   if (net->hidden == 64 && ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IFOU>), g, b, lds, st, a);
   else if (net->hidden == 64) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IJFO>), g, b, lds, st, a);
   else if (ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IFOU>), g, b, lds, st, a);
@@ -516,6 +591,28 @@ extern "C" int ppo_lstm_step_save(const ppo_lstm_net* net, const float* obs, int
   if (!save_gates || !save_cprev || !save_hprev || !save_tanhc) FAIL(-1, "bad arguments");
   return lstm_launch(net, obs, n, obs_stride, mask, c, h, state_stride, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, save_gates,
                      save_cprev, save_hprev, save_tanhc, stream);
+}
+
+extern "C" int ppo_lstm_xproj(const ppo_lstm_net* net, const float* obs, int rows, int obs_stride, float* z_out, void* stream) {
+  if (!net || !obs || !z_out || rows <= 0) FAIL(-1, "bad arguments");
+  if (net->hidden != 64 && net->hidden != 128) FAIL(-2, "hidden %d: only 64 and 128 are built", net->hidden);
+  if (net->ob_dim < 1 || net->ob_dim > 512 || obs_stride < net->ob_dim) FAIL(-3, "bad ob_dim/obs_stride");
+  if (net->emb_w || net->obs_mean || net->obs_invstd) FAIL(-4, "nets without embedding / observation filter only");
+  if (!net->wx) FAIL(-5, "missing LSTM weights");
+  const int XS = x_stride(net->ob_dim);
+  const size_t lds = (size_t)16 * XS * sizeof(float);
+  dim3 g((rows + 15) / 16), b(256);
+  if (net->hidden == 64) hipLaunchKernelGGL(ppo_lstm_xproj_kernel<64>, g, b, lds, (hipStream_t)stream, *net, obs, rows, obs_stride, z_out, XS);
+  else hipLaunchKernelGGL(ppo_lstm_xproj_kernel<128>, g, b, lds, (hipStream_t)stream, *net, obs, rows, obs_stride, z_out, XS);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int ppo_lstm_step_save_z(const ppo_lstm_net* net, const float* z_t, int n, const float* mask, float* c, float* h, int state_stride,
+                                    float* save_gates, float* save_cprev, float* save_hprev, float* save_tanhc, float* latent_out,
+                                    void* stream) {
+  if (!z_t || !save_gates || !save_cprev || !save_hprev || !save_tanhc) FAIL(-1, "bad arguments");
+  return lstm_launch(net, nullptr, n, net ? net->ob_dim : 0, mask, c, h, state_stride, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, save_gates,
+                     save_cprev, save_hprev, save_tanhc, stream, nullptr, nullptr, z_t, latent_out);
 }
 
 // ---- loss heads on stored latents: one thread per row (rows x hidden x (ac_dim + 1) MACs: small next to the recurrence)

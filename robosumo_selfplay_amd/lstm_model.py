@@ -63,6 +63,7 @@ class LstmPPOModel(object):
             self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
             self._graphs = {}
             self.wgrad_native = os.environ.get("SUMO_LSTM_WGRAD", "native") != "blas"
+            self.xproj = os.environ.get("SUMO_LSTM_XPROJ", "1") != "0"      # input block of the training forward hoisted out of the recurrence
             self.wg_workspace = torch.empty(ppo_capi.lib().ppo_lstm_wgrad_workspace_bytes(D, H, A), dtype=torch.uint8, device=self.device)
 
     class _X:
@@ -178,10 +179,20 @@ class LstmPPOModel(object):
         gates = t.empty((T, n, 4 * H), dtype=f32, device=dev)
         cprev, hprev, tanhc, lat = (t.empty((T, n, H), dtype=f32, device=dev) for _ in range(4))
         net = C.byref(self._net)
+        # the input block x * wx of all T steps in one launch; the T sequential steps then only run the recurrent block on top of it
+        # (same sums bit for bit, half the dependent chain per step).  The buffer is the one the backward sweep fills with dz later.
+        dz = t.empty((T, n, 4 * H), dtype=f32, device=dev)
+        if self.xproj:
+            ppo_capi.chk(L.ppo_lstm_xproj(net, X.data_ptr(), rows, D, dz.data_ptr(), st))
         for k in range(T):
-            ppo_capi.chk(L.ppo_lstm_step_save(net, X[k].data_ptr(), n, D, Mk[k].data_ptr(), state.data_ptr(), state.data_ptr() + 4 * H,
-                                              2 * H, gates[k].data_ptr(), cprev[k].data_ptr(), hprev[k].data_ptr(), tanhc[k].data_ptr(), st))
-            lat[k].copy_(state[:, H:])
+            if self.xproj:
+                ppo_capi.chk(L.ppo_lstm_step_save_z(net, dz[k].data_ptr(), n, Mk[k].data_ptr(), state.data_ptr(), state.data_ptr() + 4 * H, 2 * H,
+                                                    gates[k].data_ptr(), cprev[k].data_ptr(), hprev[k].data_ptr(), tanhc[k].data_ptr(),
+                                                    lat[k].data_ptr(), st))
+            else:
+                ppo_capi.chk(L.ppo_lstm_step_save(net, X[k].data_ptr(), n, D, Mk[k].data_ptr(), state.data_ptr(), state.data_ptr() + 4 * H,
+                                                  2 * H, gates[k].data_ptr(), cprev[k].data_ptr(), hprev[k].data_ptr(), tanhc[k].data_ptr(), st))
+                lat[k].copy_(state[:, H:])
         dlat = t.empty((T, n, H), dtype=f32, device=dev)
         dmean = t.empty((rows, A), dtype=f32, device=dev)
         dvalue = t.empty(rows, dtype=f32, device=dev)
@@ -192,7 +203,6 @@ class LstmPPOModel(object):
                                           dls.data_ptr(), self.stats.data_ptr(), st))
         dh = t.zeros((n, H), dtype=f32, device=dev)
         dc = t.zeros((n, H), dtype=f32, device=dev)
-        dz = t.empty((T, n, 4 * H), dtype=f32, device=dev)
         for k in range(T - 1, -1, -1):
             ppo_capi.chk(L.ppo_lstm_bwd_step(net, n, dlat[k].data_ptr(), Mk[k].data_ptr(), gates[k].data_ptr(), cprev[k].data_ptr(),
                                              tanhc[k].data_ptr(), dh.data_ptr(), dc.data_ptr(), dz[k].data_ptr(), st))

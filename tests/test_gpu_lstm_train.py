@@ -59,6 +59,32 @@ def test_bptt_gradients_match_oracle(T, n, D, A, H):
         assert np.abs(g - go.reshape(g.shape)).max() < 3e-4 * scale + 1e-7, (name, np.abs(g - go.reshape(g.shape)).max(), scale)
 
 
+@pytest.mark.parametrize("T,n,D,A,H", [(6, 37, 121, 8, 128), (4, 16, 13, 3, 64), (9, 130, 209, 16, 128)])
+def test_hoisted_input_block_is_bit_identical(T, n, D, A, H):
+    """The training forward with x * wx of all time steps computed up front (ppo_lstm_xproj + ppo_lstm_step_save_z) against the
+    step-by-step forward from the observations (ppo_lstm_step_save): the gate sums continue the same accumulation, so gradients and
+    loss sums agree bit for bit."""
+    rng = np.random.default_rng(2)
+    obs, masks, actions, returns, values, S0 = _batch(rng, T, n, D, A, H)
+    old = rng.normal(8, 1, (n, T)).astype(np.float32)
+    advs = rng.normal(0, 1, (n, T)).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, (n, T)).astype(np.float32)
+    flat = lambda x: np.ascontiguousarray(x).reshape(n * T, *x.shape[2:])
+    res = []
+    for xproj in (True, False):
+        np.random.seed(3)
+        m = lstm_model.LstmPPOModel(policy=lstm_model.LstmSpec(D, A, H), ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, nbatch_act=n, nsteps=T)
+        assert m.xproj
+        m.xproj = xproj
+        m.loss_and_grads(0.2, flat(obs), flat(returns), flat(masks), flat(actions), flat(advs), flat(old), flat(w), S0, T)
+        torch.cuda.synchronize()
+        res.append((m.grads.clone(), m.stats.clone()))
+    P = res[0][0].numel() - res[0][1].numel()
+    assert torch.equal(res[0][0][:P], res[1][0][:P]) and res[0][0][:P].abs().max() > 0
+    # (the loss sums are float64 atomics over the rows: equal up to the order of the additions)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-12, atol=1e-12)
+
+
 def test_train_step_matches_oracle_adam_and_reduces_loss():
     rng = np.random.default_rng(5)
     T, n, D, A, H = 8, 24, 19, 4, 64
