@@ -292,8 +292,11 @@ struct LstmArgs {
   int n, obs_stride, state_stride, XS, HP;
 };
 
-template <int NH, int ORDER, bool ZIN = false>   // hidden units: 64 or 128; gate order (static so the gate tiles are static registers); ZIN: gate sums start from LstmArgs::zinit
-__global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
+// NH hidden units: 64 or 128; gate order (static so the gate tiles are static registers); ZIN: gate sums start from LstmArgs::zinit;
+// NW waves per tile: 4, or 8 for NH = 128 (one unit tile per wave: half the products and half the transcendentals on a wave's chain)
+template <int NH, int ORDER, bool ZIN = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) ppo_lstm_step_kernel(LstmArgs a) {
+  constexpr int NT = 64 * NW;
   // FOUR waves per 16-row tile: wave w owns the units [w NH/4, (w+1) NH/4) -- all four gates of those units, their cell
   // update and their slice of the new latent -- so the serial chain per wave is a quarter of the tile's (one wave per tile
   // took 150 us for H = 128 whatever the batch: 63 dependent k-steps of 32 products, then 128 units of transcendentals).
@@ -305,7 +308,8 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
   float* hprev = ebuf + 16 * HS;
   float* hnew = hprev + 16 * HP;
   const int i = lane & 15, kq = lane >> 4;
-  constexpr int UT = NH / 16, UTW = UT / 4, NTW = 4 * UTW;   // unit tiles, unit tiles per wave, gate tiles per wave
+  constexpr int UT = NH / 16, UTW = UT / NW, NTW = 4 * UTW;   // unit tiles, unit tiles per wave, gate tiles per wave
+  static_assert(UTW >= 1 && UTW * NW == UT, "a whole number of unit tiles per wave");
   f32x4 z[NTW];
   if (ZIN) {   // (first thing in the kernel: these loads are in flight while the previous latent is staged)
     // the input block's partial sums come from ppo_lstm_xproj (same k order from zero): continuing the accumulation on them with
@@ -323,20 +327,51 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
 #pragma unroll
     for (int ct = 0; ct < NTW; ct++) z[ct] = (f32x4){0, 0, 0, 0};
   }
-  if (!ZIN) stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, tid, N.obs_mean, N.obs_invstd, N.obs_clip, 256);
+  // weight operands of the gate sums, by chunks of LCH k-steps (see the loop below); nothing here depends on the staged tiles
+  constexpr int LCH = 4;
+  const int xk0 = ZIN ? 0 : (N.emb_w ? E : D);
+  const int xsteps = (xk0 + 3) >> 2, nsteps = xsteps + NH / 4, nchunks = (nsteps + LCH - 1) / LCH;
+  const float PT_GAS* gwx = pt_global(N.wx);
+  const float PT_GAS* gwh = pt_global(N.wh);
+  auto fetch_w = [&](int c, float (&b)[LCH][NTW]) {
+#pragma unroll
+    for (int q = 0; q < LCH; q++) {
+      const int s_ = c * LCH + q;
+      if (s_ < xsteps) {
+        const int k = 4 * s_ + kq;
+        const bool ok = k < xk0;
+        const float PT_GAS* wrow = gwx + (size_t)(ok ? k : 0) * 4 * NH;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int u = 0; u < UTW; u++) b[q][g * UTW + u] = ok ? wrow[(g * UT + wid * UTW + u) * 16 + i] : 0.0f;
+      } else if (s_ < nsteps) {
+        const int k = 4 * (s_ - xsteps) + kq;
+        const float PT_GAS* wrow = gwh + (size_t)k * 4 * NH;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int u = 0; u < UTW; u++) b[q][g * UTW + u] = wrow[(g * UT + wid * UTW + u) * 16 + i];
+      }
+    }
+  };
+  float wring[3][LCH][NTW];
+  fetch_w(0, wring[0]);
+  if (nchunks > 1) fetch_w(1, wring[1]);
+  if (!ZIN) stage_x(xbuf, XS, a.obs, a.obs_stride, D, nullptr, r0, a.n, tid, N.obs_mean, N.obs_invstd, N.obs_clip, NT);
   // h_prev * (1 - mask): eight state loads in flight per thread
-  for (int e0 = 0; e0 < 16 * NH; e0 += 8 * 256) {
+  for (int e0 = 0; e0 < 16 * NH; e0 += 8 * NT) {
     float v[8], keep[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const int e = e0 + 256 * u + tid, r = e / NH, k = e - r * NH, row = r0 + r;
+      const int e = e0 + NT * u + tid, r = e / NH, k = e - r * NH, row = r0 + r;
       const bool in = e < 16 * NH && row < a.n;
       v[u] = in ? a.h[(size_t)row * a.state_stride + k] : 0.0f;
       keep[u] = (a.mask && in) ? 1.0f - a.mask[row] : 1.0f;
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const int e = e0 + 256 * u + tid, r = e / NH, k = e - r * NH, row = r0 + r;
+      const int e = e0 + NT * u + tid, r = e / NH, k = e - r * NH, row = r0 + r;
       if (e < 16 * NH) {
         const float hv = a.mask ? v[u] * keep[u] : v[u];
         hprev[r * HP + k] = hv;
@@ -372,39 +407,28 @@ __global__ void __launch_bounds__(256) ppo_lstm_step_kernel(LstmArgs a) {
   }
   // ---- gates z = x * wx + h_prev * wh + b for this wave's units: tiles (gate g, unit tile wid*UTW + u)
   {
-    // k-steps run over the input block (wx) and then the recurrent block (wh); the weight operands of step s+1 are
-    // loaded before the products of step s are issued (two register sets); accumulation order per tile as ever
-    const int xsteps = ZIN ? 0 : (xk + 3) >> 2, nsteps = xsteps + NH / 4;
-    auto fetch = [&](int s_, float& av, float (&b)[NTW]) {
-      if (s_ < xsteps) {
-        const int k = 4 * s_ + kq;
-        const bool ok = k < xk;
-        av = ok ? xin[i * xs + k] : 0.0f;
-        const float* wrow = N.wx + (size_t)(ok ? k : 0) * 4 * NH;
+    // k-steps run over the input block (wx) and then the recurrent block (wh), accumulation order per tile as ever.  The weight
+    // operands come from L2 (~0.5 us a trip) and a k-step's eight products take a tenth of that: chunks of four k-steps, ring of three
+    // register sets, two chunks (64 loads per lane) in flight ahead of the products -- the first two were issued at the top of the kernel
+    for (int c0 = 0; c0 < nchunks; c0 += 3) {
 #pragma unroll
-        for (int g = 0; g < 4; g++)
+      for (int b = 0; b < 3; b++) {
+        if (c0 + b + 2 < nchunks) fetch_w(c0 + b + 2, wring[(b + 2) % 3]);
+        if (c0 + b < nchunks) {
+          float av[LCH];
 #pragma unroll
-          for (int u = 0; u < UTW; u++) b[g * UTW + u] = ok ? wrow[(g * UT + wid * UTW + u) * 16 + i] : 0.0f;
-      } else {
-        const int k = 4 * (s_ - xsteps) + kq;
-        av = hprev[i * HP + k];
-        const float* wrow = N.wh + (size_t)k * 4 * NH;
+          for (int q = 0; q < LCH; q++) {
+            const int s_ = (c0 + b) * LCH + q;
+            if (s_ < xsteps) { const int k = 4 * s_ + kq; av[q] = k < xk ? xin[i * xs + k] : 0.0f; }
+            else av[q] = s_ < nsteps ? hprev[i * HP + 4 * (s_ - xsteps) + kq] : 0.0f;
+          }
 #pragma unroll
-        for (int g = 0; g < 4; g++)
+          for (int q = 0; q < LCH; q++)
+            if ((c0 + b) * LCH + q < nsteps) {
 #pragma unroll
-          for (int u = 0; u < UTW; u++) b[g * UTW + u] = wrow[(g * UT + wid * UTW + u) * 16 + i];
-      }
-    };
-    float a0 = 0.0f, a1 = 0.0f, b0[NTW], b1[NTW];
-    fetch(0, a0, b0);
-    for (int s_ = 0; s_ < nsteps; s_ += 2) {
-      if (s_ + 1 < nsteps) fetch(s_ + 1, a1, b1);
-#pragma unroll
-      for (int ct = 0; ct < NTW; ct++) z[ct] = MFMA(a0, b0[ct], z[ct]);
-      if (s_ + 2 < nsteps) fetch(s_ + 2, a0, b0);
-      if (s_ + 1 < nsteps) {
-#pragma unroll
-        for (int ct = 0; ct < NTW; ct++) z[ct] = MFMA(a1, b1[ct], z[ct]);
+              for (int ct = 0; ct < NTW; ct++) z[ct] = MFMA(av[q], wring[b][q][ct], z[ct]);
+            }
+        }
       }
     }
   }
@@ -558,11 +582,11 @@ static int lstm_launch(const ppo_lstm_net* net, const float* obs, int n, int obs
   const bool ifou = net->gate_order == PPO_LSTM_GATES_IFOU;
   dim3 g(tiles), b(256);
   hipStream_t st = (hipStream_t)stream;
-  if (zinit) {   // training forward on precomputed input sums
+  if (zinit) {   // training forward on precomputed input sums (eight waves per tile where a wave still gets a whole unit tile)
     if (net->hidden == 64 && ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IFOU, true>), g, b, lds, st, a);
     else if (net->hidden == 64) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IJFO, true>), g, b, lds, st, a);
-    else if (ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IFOU, true>), g, b, lds, st, a);
-    else hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IJFO, true>), g, b, lds, st, a);
+    else if (ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IFOU, true, 8>), g, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((ppo_lstm_step_kernel<128, PPO_LSTM_GATES_IJFO, true, 8>), g, dim3(512), lds, st, a);
   } else
   if (net->hidden == 64 && ifou) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IFOU>), g, b, lds, st, a);
   else if (net->hidden == 64) hipLaunchKernelGGL((ppo_lstm_step_kernel<64, PPO_LSTM_GATES_IJFO>), g, b, lds, st, a);
