@@ -105,6 +105,17 @@ int ppo_lstm_step_save(const ppo_lstm_net* net, const float* obs, int n, int obs
 int ppo_lstm_xproj(const ppo_lstm_net* net, const float* obs, int rows, int obs_stride, float* z_out, void* stream);
 int ppo_lstm_step_save_z(const ppo_lstm_net* net, const float* z_t, int n, const float* mask, float* c, float* h, int state_stride,
                          float* save_gates, float* save_cprev, float* save_hprev, float* save_tanhc, float* latent_out, void* stream);
+/* All T steps in one launch each (hidden 128, gate order i,f,o,u): a workgroup of eight waves owns a 16-row tile of env sequences for
+ * the whole sequence and keeps its slice of wh in registers; time-major buffers [T][n][...], mask [T][n] (NULL = none).
+ *   ppo_lstm_seq_forward   z0 = ppo_lstm_xproj of all rows; c / h [n] (state_stride) hold the state at the start and receive the state
+ *                          after step T-1; records as ppo_lstm_step_save per step + latent [T][n][128].  Same numbers as T calls of
+ *                          ppo_lstm_step_save_z, bit for bit.
+ *   ppo_lstm_seq_backward  BPTT from zero carries: dz_out [T][n][512] as T calls of ppo_lstm_bwd_step from t = T-1 down (the
+ *                          contraction dz * wh^T is summed in one chain instead of four partial tiles: equal up to rounding). */
+int ppo_lstm_seq_forward(const ppo_lstm_net* net, const float* z0, int T, int n, const float* mask, float* c, float* h, int state_stride,
+                         float* save_gates, float* save_cprev, float* save_hprev, float* save_tanhc, float* latent, void* stream);
+int ppo_lstm_seq_backward(const ppo_lstm_net* net, int T, int n, const float* dlatent, const float* mask, const float* gates,
+                          const float* cprev, const float* tanhc, float* dz_out, void* stream);
 /* PPO loss heads on stored latents (rows = all (time, env) pairs of the minibatch): forward of the Gaussian / value heads,
  * loss terms of model.py:65-111 and their gradients.  Outputs: dlatent [rows][hidden], dmean [rows][ac_dim], dvalue [rows],
  * dlogstd_rows [rows][ac_dim] (sum over rows - ent_coef = d loss / d logstd), stats double[PPO_NSTATS] (+= un-normalised sums

@@ -815,6 +815,203 @@ extern "C" int ppo_lstm_bwd_step(const ppo_lstm_net* net, int n, const float* dl
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The T steps of the unrolled forward / of BPTT in ONE launch each (hidden 128, gate order i,f,o,u).  A training minibatch is a few
+// 16-row tiles of env sequences (128 envs = 8 tiles) whose time steps depend on each other: launched step by step, every step pays a
+// launch boundary and re-reads the recurrent weights from L2.  Here a workgroup of EIGHT waves owns a tile for the whole sequence; wave
+// w owns the units 16 w .. 16 w + 15 and keeps ITS SLICE OF wh IN REGISTERS for all T steps (forward: the 4 x 32 B operands of its four
+// gate tiles, backward: the 128 B operands of its output tile of dz * wh^T; 128 floats per lane either way), the cell / delta carries
+// live in registers in the MFMA D layout (lane (i, kq): rows 4 kq + r, unit 16 w + i), the latent / the deltas cross the waves
+// through a double-buffered LDS tile (one barrier per step), and the next step's global operands are requested during the products.
+// ---------------------------------------------------------------------------------------------------------
+struct LstmSeqArgs {
+  const float *wh, *b; float forget_bias;
+  const float* z0;        // [T][n][512] input sums (ppo_lstm_xproj)
+  const float* mask;      // [T][n]
+  float *c, *h; int state_stride;
+  float *sv_gates, *sv_cprev, *sv_hprev, *sv_tanhc, *latent;   // [T][n][...]
+  const float* dlat;      // backward: [T][n][128]
+  float* dz;              // backward: [T][n][512]
+  int T, n;
+};
+
+__global__ void __launch_bounds__(512) ppo_lstm_seq_fwd_kernel(LstmSeqArgs a) {
+  constexpr int NH = 128, HP = NH + 4;
+  float* hbuf = smem_f;                // [2][16][HP]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r0 = blockIdx.x * 16;
+  const int i = lane & 15, kq = lane >> 4, j = 16 * w + i;
+  // this lane's B operands: k-step s (k = 4 s + kq), gate g, column g * NH + j
+  float W[32][4];
+#pragma unroll
+  for (int s_ = 0; s_ < 32; s_++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) W[s_][g] = a.wh[(size_t)(4 * s_ + kq) * 4 * NH + g * NH + j];
+  const float bi = a.b[j], bf = a.b[NH + j] + a.forget_bias, bo = a.b[2 * NH + j], bu = a.b[3 * NH + j];
+  float c[4], keep[4];
+  f32x4 z[4];
+  auto load_z = [&](int t, f32x4 (&zz)[4], float (&kp)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 4 * kq + r;
+      const bool ok = row < a.n;
+      kp[r] = (ok && a.mask) ? 1.0f - a.mask[(size_t)t * a.n + row] : 1.0f;
+#pragma unroll
+      for (int g = 0; g < 4; g++) zz[g][r] = ok ? a.z0[((size_t)t * a.n + row) * 4 * NH + g * NH + j] : 0.0f;
+    }
+  };
+  load_z(0, z, keep);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = r0 + 4 * kq + r;
+    float h0 = 0.0f;
+    c[r] = 0.0f;
+    if (row < a.n) { c[r] = a.c[(size_t)row * a.state_stride + j]; h0 = a.h[(size_t)row * a.state_stride + j]; }
+    const float hv = h0 * keep[r];
+    hbuf[(4 * kq + r) * HP + j] = hv;
+    if (row < a.n) a.sv_hprev[(size_t)row * NH + j] = hv;
+  }
+  float hn_last[4] = {0, 0, 0, 0};
+  for (int t = 0; t < a.T; t++) {
+    const float* hb = hbuf + (t & 1) * 16 * HP;
+    float* hb_next = hbuf + ((t + 1) & 1) * 16 * HP;
+    __syncthreads();   // the masked previous latent of every unit is in hb
+    f32x4 zn[4];
+    float keepn[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (t + 1 < a.T) load_z(t + 1, zn, keepn);   // in flight during the products
+#pragma unroll
+    for (int s_ = 0; s_ < 32; s_++) {
+      const float av = hb[i * HP + 4 * s_ + kq];
+#pragma unroll
+      for (int g = 0; g < 4; g++) z[g] = MFMA(av, W[s_][g], z[g]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 4 * kq + r;
+      const float cp = c[r] * keep[r];
+      const LstmCell cell = lstm_cell(z[0][r], z[1][r], z[2][r], z[3][r], bi, bf, bo, bu, cp);
+      c[r] = cell.cn; hn_last[r] = cell.hn;
+      const float hv = cell.hn * keepn[r];              // what the next step reads: masked by ITS done flag
+      hb_next[(4 * kq + r) * HP + j] = hv;
+      if (row < a.n) {
+        const size_t o = ((size_t)t * a.n + row) * NH + j;
+        float* sg = a.sv_gates + ((size_t)t * a.n + row) * 4 * NH;
+        sg[j] = cell.ig; sg[NH + j] = cell.fg; sg[2 * NH + j] = cell.og; sg[3 * NH + j] = cell.ug;
+        a.sv_cprev[o] = cp; a.sv_tanhc[o] = cell.tcn; a.latent[o] = cell.hn;
+        if (t + 1 < a.T) a.sv_hprev[o + (size_t)a.n * NH] = hv;
+      }
+    }
+    if (t + 1 < a.T) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) z[g] = zn[g];
+#pragma unroll
+      for (int r = 0; r < 4; r++) keep[r] = keepn[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = r0 + 4 * kq + r;
+    if (row < a.n) { a.c[(size_t)row * a.state_stride + j] = c[r]; a.h[(size_t)row * a.state_stride + j] = hn_last[r]; }
+  }
+}
+
+__global__ void __launch_bounds__(512) ppo_lstm_seq_bwd_kernel(LstmSeqArgs a) {
+  constexpr int NH = 128, ZS = 4 * NH + 4;
+  float* dzb = smem_f;                 // [2][16][ZS]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r0 = blockIdx.x * 16;
+  const int i = lane & 15, kq = lane >> 4, j = 16 * w + i;
+  // B operands of dh_prev = dz * wh^T for this wave's output tile: B[k = column][unit j] = wh[j][column], k-step s: column 4 s + kq
+  float W[128];
+#pragma unroll
+  for (int s_ = 0; s_ < 128; s_++) W[s_] = a.wh[(size_t)j * 4 * NH + 4 * s_ + kq];
+  float dh[4] = {0, 0, 0, 0}, dc[4] = {0, 0, 0, 0};
+  struct In { float ig, fg, og, ug, tc, cp, dl, keep; };
+  auto load_in = [&](int t, In (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 4 * kq + r;
+      v[r] = In{0, 0, 0, 0, 0, 0, 0, 1.0f};
+      if (row < a.n) {
+        const size_t o = ((size_t)t * a.n + row) * NH + j;
+        const float* g = a.sv_gates + ((size_t)t * a.n + row) * 4 * NH;
+        v[r].ig = g[j]; v[r].fg = g[NH + j]; v[r].og = g[2 * NH + j]; v[r].ug = g[3 * NH + j];
+        v[r].tc = a.sv_tanhc[o]; v[r].cp = a.sv_cprev[o]; v[r].dl = a.dlat[o];
+        if (a.mask) v[r].keep = 1.0f - a.mask[(size_t)t * a.n + row];
+      }
+    }
+  };
+  In cur[4], nxt[4];
+  load_in(a.T - 1, cur);
+  for (int t = a.T - 1; t >= 0; t--) {
+    float* zb = dzb + (t & 1) * 16 * ZS;
+    if (t > 0) load_in(t - 1, nxt);      // in flight during this step
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = r0 + 4 * kq + r;
+      const In& v = cur[r];
+      float dzi = 0, dzf = 0, dzo = 0, dzu = 0;
+      if (row < a.n) {
+        const float dht = v.dl + dh[r];
+        const float dct = dc[r] + dht * v.og * (1.0f - v.tc * v.tc);
+        dzi = dct * v.ug * v.ig * (1.0f - v.ig); dzf = dct * v.cp * v.fg * (1.0f - v.fg); dzo = dht * v.tc * v.og * (1.0f - v.og);
+        dzu = dct * v.ig * (1.0f - v.ug * v.ug);
+        dc[r] = dct * v.fg * v.keep;
+        float* zo = a.dz + ((size_t)t * a.n + row) * 4 * NH;
+        zo[j] = dzi; zo[NH + j] = dzf; zo[2 * NH + j] = dzo; zo[3 * NH + j] = dzu;
+      }
+      float* zr = zb + (4 * kq + r) * ZS;
+      zr[j] = dzi; zr[NH + j] = dzf; zr[2 * NH + j] = dzo; zr[3 * NH + j] = dzu;
+    }
+    __syncthreads();   // the tile's deltas of step t are in zb (the other buffer is free again: its readers passed this barrier)
+    f32x4 acc0 = (f32x4){0, 0, 0, 0}, acc1 = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int s_ = 0; s_ < 128; s_ += 2) {
+      acc0 = MFMA(zb[i * ZS + 4 * s_ + kq], W[s_], acc0);
+      acc1 = MFMA(zb[i * ZS + 4 * (s_ + 1) + kq], W[s_ + 1], acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) dh[r] = (acc0[r] + acc1[r]) * cur[r].keep;
+    if (t > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) cur[r] = nxt[r];
+    }
+  }
+}
+
+static int lstm_seq_check(const ppo_lstm_net* net, int T, int n) {
+  if (!net || !net->wh || !net->b || T <= 0 || n <= 0) FAIL(-1, "bad arguments");
+  if (net->hidden != 128 || net->gate_order != PPO_LSTM_GATES_IFOU) FAIL(-2, "sequence kernels: hidden 128, gate order i,f,o,u (got %d, %d)", net->hidden, net->gate_order);
+  return 0;
+}
+extern "C" int ppo_lstm_seq_forward(const ppo_lstm_net* net, const float* z0, int T, int n, const float* mask, float* c, float* h, int state_stride,
+                                    float* save_gates, float* save_cprev, float* save_hprev, float* save_tanhc, float* latent, void* stream) {
+  if (int rc = lstm_seq_check(net, T, n)) return rc;
+  if (!z0 || !c || !h || !save_gates || !save_cprev || !save_hprev || !save_tanhc || !latent || state_stride < 128) FAIL(-1, "bad arguments");
+  LstmSeqArgs a = LstmSeqArgs();
+  a.wh = net->wh; a.b = net->b; a.forget_bias = net->forget_bias; a.z0 = z0; a.mask = mask; a.c = c; a.h = h; a.state_stride = state_stride;
+  a.sv_gates = save_gates; a.sv_cprev = save_cprev; a.sv_hprev = save_hprev; a.sv_tanhc = save_tanhc; a.latent = latent; a.T = T; a.n = n;
+  const size_t lds = (size_t)2 * 16 * (128 + 4) * sizeof(float);
+  hipLaunchKernelGGL(ppo_lstm_seq_fwd_kernel, dim3((n + 15) / 16), dim3(512), lds, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int ppo_lstm_seq_backward(const ppo_lstm_net* net, int T, int n, const float* dlatent, const float* mask, const float* gates,
+                                     const float* cprev, const float* tanhc, float* dz_out, void* stream) {
+  if (int rc = lstm_seq_check(net, T, n)) return rc;
+  if (!dlatent || !gates || !cprev || !tanhc || !dz_out) FAIL(-1, "bad arguments");
+  LstmSeqArgs a = LstmSeqArgs();
+  a.wh = net->wh; a.mask = mask; a.sv_gates = const_cast<float*>(gates); a.sv_cprev = const_cast<float*>(cprev); a.sv_tanhc = const_cast<float*>(tanhc);
+  a.dlat = dlatent; a.dz = dz_out; a.T = T; a.n = n;
+  const size_t lds = (size_t)2 * 16 * (4 * 128 + 4) * sizeof(float);
+  static thread_local bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)ppo_lstm_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ppo_lstm_seq_bwd_kernel, dim3((n + 15) / 16), dim3(512), lds, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Weight gradients of the recurrent PPO step: C = A'^T B over all (time, env) rows of the minibatch, A' = [A0 | A1 | 1]
 // (input, previous hidden state, ones column for the bias), B = [B0 | B1 | B2] (gate / head deltas).  The contraction runs
 // over the ROWS (thousands), the output is small (250 x 512): split-K over workgroups -- every workgroup owns a chunk of rows,

@@ -63,6 +63,7 @@ class LstmPPOModel(object):
             self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
             self._graphs = {}
             self.wgrad_native = os.environ.get("SUMO_LSTM_WGRAD", "native") != "blas"
+            self.seq_kernels = os.environ.get("SUMO_LSTM_SEQ", "1") != "0"    # whole-sequence forward / BPTT launches (nlstm 128)
             self.xproj = os.environ.get("SUMO_LSTM_XPROJ", "1") != "0"      # input block of the training forward hoisted out of the recurrence
             self.wg_workspace = torch.empty(ppo_capi.lib().ppo_lstm_wgrad_workspace_bytes(D, H, A), dtype=torch.uint8, device=self.device)
 
@@ -184,7 +185,11 @@ class LstmPPOModel(object):
         dz = t.empty((T, n, 4 * H), dtype=f32, device=dev)
         if self.xproj:
             ppo_capi.chk(L.ppo_lstm_xproj(net, X.data_ptr(), rows, D, dz.data_ptr(), st))
-        for k in range(T):
+        seq = self.xproj and self.seq_kernels and H == 128      # all T steps in one launch, recurrent weights resident in registers
+        if seq:
+            ppo_capi.chk(L.ppo_lstm_seq_forward(net, dz.data_ptr(), T, n, Mk.data_ptr(), state.data_ptr(), state.data_ptr() + 4 * H, 2 * H,
+                                                gates.data_ptr(), cprev.data_ptr(), hprev.data_ptr(), tanhc.data_ptr(), lat.data_ptr(), st))
+        for k in range(0 if seq else T):
             if self.xproj:
                 ppo_capi.chk(L.ppo_lstm_step_save_z(net, dz[k].data_ptr(), n, Mk[k].data_ptr(), state.data_ptr(), state.data_ptr() + 4 * H, 2 * H,
                                                     gates[k].data_ptr(), cprev[k].data_ptr(), hprev[k].data_ptr(), tanhc[k].data_ptr(),
@@ -201,9 +206,12 @@ class LstmPPOModel(object):
         ppo_capi.chk(L.ppo_lstm_head_grad(net, lat.data_ptr(), rows, Ac.data_ptr(), Ad.data_ptr(), R.data_ptr(), Old.data_ptr(), W.data_ptr(),
                                           1.0 / (rows * world), float(cliprange), self.vf_coef, dlat.data_ptr(), dmean.data_ptr(), dvalue.data_ptr(),
                                           dls.data_ptr(), self.stats.data_ptr(), st))
+        if seq:
+            ppo_capi.chk(L.ppo_lstm_seq_backward(net, T, n, dlat.data_ptr(), Mk.data_ptr(), gates.data_ptr(), cprev.data_ptr(), tanhc.data_ptr(),
+                                                 dz.data_ptr(), st))
         dh = t.zeros((n, H), dtype=f32, device=dev)
         dc = t.zeros((n, H), dtype=f32, device=dev)
-        for k in range(T - 1, -1, -1):
+        for k in range(-1 if seq else T - 1, -1, -1):
             ppo_capi.chk(L.ppo_lstm_bwd_step(net, n, dlat[k].data_ptr(), Mk[k].data_ptr(), gates[k].data_ptr(), cprev[k].data_ptr(),
                                              tanhc[k].data_ptr(), dh.data_ptr(), dc.data_ptr(), dz[k].data_ptr(), st))
         # weight gradients: [x | h_prev | 1]^T dz and [latent | 1]^T [dmean | dvalue | dlogstd rows] over all (time, env) rows, on the

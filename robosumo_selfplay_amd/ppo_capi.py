@@ -9,7 +9,7 @@ FWD_PI, FWD_VF, FWD_TANH = 1, 2, 4
 LSTM_GATES_IFOU, LSTM_GATES_IJFO = 0, 1
 _LIB = None
 
-EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_forward_filtered", "ppo_lstm_step", "ppo_lstm_step_pool", "ppo_lstm_step_save", "ppo_lstm_xproj", "ppo_lstm_step_save_z", "ppo_lstm_head_grad", "ppo_lstm_bwd_step", "ppo_lstm_wgrad_workspace_bytes", "ppo_lstm_wgrad", "ppo_selfplay_forward", "ppo_post_step", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
+EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_forward_filtered", "ppo_lstm_step", "ppo_lstm_step_pool", "ppo_lstm_step_save", "ppo_lstm_xproj", "ppo_lstm_step_save_z", "ppo_lstm_seq_forward", "ppo_lstm_seq_backward", "ppo_lstm_head_grad", "ppo_lstm_bwd_step", "ppo_lstm_wgrad_workspace_bytes", "ppo_lstm_wgrad", "ppo_selfplay_forward", "ppo_post_step", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
            "ppo_adv_normalize", "ppo_grad_workspace_bytes", "ppo_grad", "ppo_loss_stats", "ppo_clip_adam")
 
 
@@ -42,6 +42,8 @@ def lib():
         L.ppo_lstm_step_save.argtypes = [C.POINTER(LstmNet), vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
         L.ppo_lstm_xproj.argtypes = [C.POINTER(LstmNet), vp, i32, i32, vp, vp]
         L.ppo_lstm_step_save_z.argtypes = [C.POINTER(LstmNet), vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+        L.ppo_lstm_seq_forward.argtypes = [C.POINTER(LstmNet), vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+        L.ppo_lstm_seq_backward.argtypes = [C.POINTER(LstmNet), i32, i32, vp, vp, vp, vp, vp, vp, vp]
         L.ppo_lstm_head_grad.argtypes = [C.POINTER(LstmNet), vp, i32, vp, vp, vp, vp, vp, f64, f32, f32, vp, vp, vp, vp, vp, vp]
         L.ppo_lstm_bwd_step.argtypes = [C.POINTER(LstmNet), i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.ppo_lstm_wgrad_workspace_bytes.argtypes = [i32, i32, i32]

@@ -76,6 +76,7 @@ def test_hoisted_input_block_is_bit_identical(T, n, D, A, H):
         m = lstm_model.LstmPPOModel(policy=lstm_model.LstmSpec(D, A, H), ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, nbatch_act=n, nsteps=T)
         assert m.xproj
         m.xproj = xproj
+        m.seq_kernels = False                    # step-by-step launches on both sides (the whole-sequence kernels have their own test)
         m.loss_and_grads(0.2, flat(obs), flat(returns), flat(masks), flat(actions), flat(advs), flat(old), flat(w), S0, T)
         torch.cuda.synchronize()
         res.append((m.grads.clone(), m.stats.clone()))
@@ -83,6 +84,39 @@ def test_hoisted_input_block_is_bit_identical(T, n, D, A, H):
     assert torch.equal(res[0][0][:P], res[1][0][:P]) and res[0][0][:P].abs().max() > 0
     # (the loss sums are float64 atomics over the rows: equal up to the order of the additions)
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("T,n,D,A", [(6, 37, 121, 8), (33, 128, 121, 8), (5, 16, 13, 3)])
+def test_sequence_kernels_match_step_kernels(T, n, D, A):
+    """Whole-sequence forward / BPTT launches (ppo_lstm_seq_forward / _backward: recurrent weights resident in registers, one launch for
+    all T steps) against the launch-per-step kernels: the forward is bit-identical (final state, loss sums up to the order of the
+    float64 atomics); the backward sums dz * wh^T in one chain instead of four partial tiles -> gradients agree to 2e-6 of each
+    tensor's scale."""
+    H = 128
+    rng = np.random.default_rng(5)
+    obs, masks, actions, returns, values, S0 = _batch(rng, T, n, D, A, H)
+    old = rng.normal(8, 1, (n, T)).astype(np.float32)
+    advs = rng.normal(0, 1, (n, T)).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, (n, T)).astype(np.float32)
+    flat = lambda x: np.ascontiguousarray(x).reshape(n * T, *x.shape[2:])
+    res = []
+    for seq in (True, False):
+        np.random.seed(3)
+        m = lstm_model.LstmPPOModel(policy=lstm_model.LstmSpec(D, A, H), ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, nbatch_act=n, nsteps=T)
+        pl = [p + rng.normal(0, 0.05, p.shape).astype(np.float32) for p in m.get_param_list()] if seq else pl
+        m.set_param_list(pl)
+        assert m.seq_kernels and m.xproj
+        m.seq_kernels = seq
+        state = m.loss_and_grads(0.2, flat(obs), flat(returns), flat(masks), flat(actions), flat(advs), flat(old), flat(w), S0, T)
+        torch.cuda.synchronize()
+        res.append(([g.clone() for g in m.gviews], m.stats.clone(), state.clone()))
+    assert torch.equal(res[0][2], res[1][2])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-12, atol=1e-12)
+    for name, a, b in zip(lstm_model.policies.LSTM_PARAM_NAMES, res[0][0], res[1][0]):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) < 2e-6 * scale, (name, float((a - b).abs().max()), scale)
+        if name in ("pi/w", "pi/b", "pi/logstd", "vf/w", "vf/b"):                       # head gradients depend on the forward only
+            assert torch.equal(a, b), name
 
 
 def test_train_step_matches_oracle_adam_and_reduces_loss():
