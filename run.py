@@ -37,8 +37,8 @@ def main(argv):
     ap.add_argument("--algo", default="ppo")
     ap.add_argument("--log_path", default="results")
     ap.add_argument("--suffix", default="0")
-    ap.add_argument("--env_groups", type=int, default=0, help="env groups per GPU (vec_env.SumoVecEnv): 0 = 1 for MLP policies (their whole "
-                    "rollout is one fused launch that balances the envs itself), 2 for recurrent policies (step-by-step launches on two streams)")
+    ap.add_argument("--env_groups", type=int, default=0, help="env groups per GPU (vec_env.SumoVecEnv): 0 = 1 when the whole rollout is one fused "
+                    "launch that balances the envs itself (MLP policies, LSTM policies with nlstm 128), 2 for step-by-step launches on two streams")
     args, unknown = ap.parse_known_args(argv)
     extra = parse_unknown(unknown)
     from robosumo_selfplay_amd import alg_ppo, defaults, dist as sdist
@@ -51,7 +51,8 @@ def main(argv):
         os.makedirs(log_path, exist_ok=True)
     start, per = sdist.shard_envs(args.num_env, rank, world)
     if args.env_groups <= 0:
-        args.env_groups = 2 if (args.network == "lstm" or os.environ.get("SUMO_FUSED_ROLLOUT", "1") == "0") else 1
+        stepwise = os.environ.get("SUMO_FUSED_ROLLOUT", "1") == "0" or (args.network == "lstm" and int(extra.get("nlstm", 128)) != 128)
+        args.env_groups = 2 if stepwise else 1
     groups = args.env_groups if per % max(1, args.env_groups) == 0 else 1
     import torch
     local_rank = local_rank % max(1, torch.cuda.device_count())        # gloo rehearsal of N ranks on fewer GPUs
