@@ -74,6 +74,14 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
   f32x4 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
+  // the biases of all three layers are requested first: read where they are used, each sat behind its own memory round trip
+  // (load, wait, add -- per column tile and layer: the compiler does not move a load across the row-guard branches around the
+  // activation stores), which was most of the phase's time in the rollout kernel
+  float bias0[4], bias1[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) { bias0[ct] = net.b0[ct * 16 + i]; bias1[ct] = net.b1[ct * 16 + i]; }
+  const bool col_ok = i < net.nout;
+  const float bias2 = net.b2[col_ok ? i : 0];
   // k-steps are issued eight at a time with all of their operand loads in flight first (32 weight loads per batch): the
   // accumulation order is unchanged, but one memory round trip is exposed per batch instead of one per k-step
   for (int k0 = 0; k0 < Dp; k0 += 32) {
@@ -82,9 +90,11 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
     for (int u = 0; u < 8; u++) {
       const int k = k0 + 4 * u + kq;
       const bool ok = k < D;
-      a[u] = (ok && (ROWS == 16 || i < ROWS)) ? xbuf[i * XS + k] : 0.0f;
+      const int kc = ok ? k : D - 1;   // unconditional loads from a clamped row, zeroed by a select (a guarded load is a branch)
+      const float av = xbuf[(ROWS == 16 ? i : (i < ROWS ? i : 0)) * XS + kc];
+      a[u] = (ok && (ROWS == 16 || i < ROWS)) ? av : 0.0f;
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) b[u][ct] = ok ? net.w0[k * PT_H + ct * 16 + i] : 0.0f;
+      for (int ct = 0; ct < 4; ct++) { const float wv = net.w0[kc * PT_H + ct * 16 + i]; b[u][ct] = ok ? wv : 0.0f; }
     }
 #pragma unroll
     for (int u = 0; u < 8; u++)
@@ -95,7 +105,7 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
   }
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
-    float bias = net.b0[ct * 16 + i];
+    const float bias = bias0[ct];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       float z = acc[ct][r] + bias;
@@ -110,16 +120,18 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
     for (int u = 0; u < PT_H / 4; u++)
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) b[u][ct] = net.w1[(4 * u + kq) * PT_H + ct * 16 + i];
+    float av[PT_H / 4];   // the tile's A operands in one batch of LDS reads
+#pragma unroll
+    for (int u = 0; u < PT_H / 4; u++) { const float v = h1buf[(ROWS == 16 ? i : (i < ROWS ? i : 0)) * PT_HS + 4 * u + kq]; av[u] = (ROWS == 16 || i < ROWS) ? v : 0.0f; }
 #pragma unroll
     for (int u = 0; u < PT_H / 4; u++) {
-      const float a = (ROWS == 16 || i < ROWS) ? h1buf[i * PT_HS + 4 * u + kq] : 0.0f;
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[ct] = PT_MFMA(a, b[u][ct], acc[ct]);
+      for (int ct = 0; ct < 4; ct++) acc[ct] = PT_MFMA(av[u], b[u][ct], acc[ct]);
     }
   }
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
-    float bias = net.b1[ct * 16 + i];
+    const float bias = bias1[ct];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       float z = acc[ct][r] + bias;
@@ -128,15 +140,16 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
   }
   wave_sync();
   f32x4 out = (f32x4){0, 0, 0, 0};
-  const bool col_ok = i < net.nout;
   {
-    float b[PT_H / 4];
+    float b[PT_H / 4], av[PT_H / 4];
 #pragma unroll
-    for (int u = 0; u < PT_H / 4; u++) b[u] = col_ok ? net.w2[(4 * u + kq) * net.nout + i] : 0.0f;
+    for (int u = 0; u < PT_H / 4; u++) { const float wv = net.w2[(4 * u + kq) * net.nout + (col_ok ? i : 0)]; b[u] = col_ok ? wv : 0.0f; }
 #pragma unroll
-    for (int u = 0; u < PT_H / 4; u++) out = PT_MFMA((ROWS == 16 || i < ROWS) ? h2buf[i * PT_HS + 4 * u + kq] : 0.0f, b[u], out);
+    for (int u = 0; u < PT_H / 4; u++) { const float v = h2buf[(ROWS == 16 ? i : (i < ROWS ? i : 0)) * PT_HS + 4 * u + kq]; av[u] = (ROWS == 16 || i < ROWS) ? v : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < PT_H / 4; u++) out = PT_MFMA(av[u], b[u], out);
   }
-  float bias = col_ok ? net.b2[i] : 0.0f;
+  float bias = col_ok ? bias2 : 0.0f;
 #pragma unroll
   for (int r = 0; r < 4; r++) out[r] += bias;
   return out;
