@@ -2225,6 +2225,13 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
 // records the mixed reward and the episode statistics.  No launch boundary, no policy launch and no per-step barrier over
 // the envs remain between two env steps; each env may face its own frozen opponent snapshot (opp_idx).
 // ---------------------------------------------------------------------------------------------------------
+#ifdef SUMO_POLICY_PROBE   /* development build: the per-env phase clock also splits the MLP policy phase (tools/fused_probe.py --probe) */
+#define PROF_STRIDE 12
+#define PPROBE(slot) do { if (r.prof && lane == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(r.prof + PROF_STRIDE * e + (slot), t_ - tp_); tp_ = t_; } } while (0)
+#else
+#define PROF_STRIDE 4
+#define PPROBE(slot) do { } while (0)
+#endif
 struct RolloutArgs {
   const float *learner, *opponent;   // flat parameter vectors; opponent: [npool][P]
   const int32_t* opp_idx;            // [N] snapshot per env or NULL
@@ -2257,6 +2264,9 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const SA& a, const RA
   const size_t slot0 = ((size_t)0 * r.T + s) * r.Ntot + col, slot1 = ((size_t)1 * r.T + s) * r.Ntot + col;
   // the env's two observations: into the tile and into the rollout record (runner.py:98-101)
   const float* ob = a.obs + (size_t)e * 2 * a.obs_stride;
+#ifdef SUMO_POLICY_PROBE
+  unsigned long long tp_ = wall_clock64();
+#endif
   for (int k = lane; k < D; k += WAVE) {
     const float o0 = hand_load<true>(ob + k), o1 = hand_load<true>(ob + a.obs_stride + k);
     xbuf[k] = o0; xbuf[XS + k] = o1;
@@ -2266,11 +2276,15 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const SA& a, const RA
   wave_sync();
   const float PT_GAS* lp = pt_global(r.learner);
   const float PT_GAS* op = pt_global(r.opponent) + (size_t)(r.opp_idx ? pt_global(r.opp_idx)[e] : 0) * r.L.P;
+  PPROBE(4);
   const f32x4 mL = trunk_forward<false, 2>(pi_net((const float*)lp, r.L), xbuf, XS, D, h1, h2, lane);
   wave_sync();
+  PPROBE(5);
   const f32x4 mO = trunk_forward<false, 2>(pi_net((const float*)op, r.L), xbuf, XS, D, h1, h2, lane);
   wave_sync();
+  PPROBE(6);
   const f32x4 vL = trunk_forward<false, 2>(vf_net((const float*)lp, r.L), xbuf, XS, D, h1, h2, lane);
+  PPROBE(7);
   // heads: row 0 = agent 0 (learner acts, opponent scores), row 1 = agent 1 (opponent acts, learner scores and values)
   const bool colk = i < A;
   const float lsL = colk ? lp[r.L.logstd + i] : 0.0f, lsO = colk ? op[r.L.logstd + i] : 0.0f;
@@ -2295,6 +2309,7 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const SA& a, const RA
     pt_global(r.nlp)[slot0] = nlp0; pt_global(r.nlp)[slot1] = nlp1; pt_global(r.onlp)[slot0] = onlp0; pt_global(r.onlp)[slot1] = onlp1;
     pt_global(r.val)[slot0] = vL[0]; pt_global(r.val)[slot1] = vL[1];
   }
+  PPROBE(8);
   wave_sync();   // the action buffer is read back by the env step (other lanes), the scratch region becomes the mass matrix again
 }
 
@@ -2501,11 +2516,11 @@ sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
     // the caller zeroes the buffer: [4e] first start, [4e+1] last end, [4e+2] ticks in policy phases, [4e+3] ticks in env steps
     unsigned long long* prof = lp->r.prof;
     unsigned long long t0 = 0;
-    if (prof && c.lane == 0) { t0 = wall_clock64(); if (k == 0) atomicExch(prof + 4 * e, t0); }
+    if (prof && c.lane == 0) { t0 = wall_clock64(); if (k == 0) atomicExch(prof + PROF_STRIDE * e, t0); }
     if constexpr (POLICY == 1) rollout_policy_phase_lstm<128>(c, lp->a, lp->r, e, s);
     else rollout_policy_phase(c, lp->a, lp->r, e, s);
     prof = launder_sptr(LP)->r.prof;
-    if (prof && c.lane == 0) { const unsigned long long t1 = wall_clock64(); atomicAdd(prof + 4 * e + 2, t1 - t0); S(stash)[11] = __longlong_as_double((long long)t1); }
+    if (prof && c.lane == 0) { const unsigned long long t1 = wall_clock64(); atomicAdd(prof + PROF_STRIDE * e + 2, t1 - t0); S(stash)[11] = __longlong_as_double((long long)t1); }
     env_step_body<true>(c, launder_sptr(LP)->a, e);
     SYNC();
     { const int* tk = (const int*)(S(stash) + 4); e = __builtin_amdgcn_readfirstlane(tk[0]); k = __builtin_amdgcn_readfirstlane(tk[1]); }
@@ -2516,7 +2531,7 @@ sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
     prof = lp->r.prof;
     if (prof && c.lane == 0) {
       const unsigned long long t2 = wall_clock64(), t1 = (unsigned long long)__double_as_longlong(S(stash)[11]);
-      atomicAdd(prof + 4 * e + 3, t2 - t1); atomicMax(prof + 4 * e + 1, t2);
+      atomicAdd(prof + PROF_STRIDE * e + 3, t2 - t1); atomicMax(prof + PROF_STRIDE * e + 1, t2);
     }
     // hand the env over: every sc1 store of the step has reached memory (vmcnt = 0), then the progress counter
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

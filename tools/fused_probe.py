@@ -13,6 +13,7 @@ ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--env-id", default="RoboSumo-Ant-vs-Ant-v0")
 ap.add_argument("--configs", default="2:0:0,1:1:0,1:1:0")
+ap.add_argument("--probe", action="store_true", help="library built with -DSUMO_POLICY_PROBE (SUMO_HIP_LIB): split of the MLP policy phase")
 ap.add_argument("--lstm", type=int, default=0, help="recurrent policies (LSTM(128)); value = opponent pool size (1 = a single opponent model)")
 a = ap.parse_args()
 for cfg in a.configs.split(","):
@@ -52,7 +53,7 @@ for cfg in a.configs.split(","):
     dt = time.perf_counter() - t0
     print("groups %d fused %d chunk %d: %.3f ms/step, %.0f env-steps/s" % (groups, fused, chunk or a.steps, dt / a.steps * 1e3, a.envs * a.steps / dt), flush=True)
     if fused and groups == 1:
-        stamps = torch.zeros((a.envs, 4), dtype=torch.int64, device=env.device)
+        stamps = torch.zeros((a.envs, 12 if a.probe else 4), dtype=torch.int64, device=env.device)
         env.engine.debug_trace(stamps.data_ptr())
         run(); torch.cuda.synchronize()   # (one launch: chunk = steps)
         env.engine.debug_trace(None)
@@ -62,4 +63,7 @@ for cfg in a.configs.split(","):
         print("  per env step: policy phase %.1f us, env step %.1f us (max env total %.2f ms, mean %.2f ms) | launch span %.2f ms, slot-time busy %.1f %% "
               "of 2048 slots | aborts %d" % (pol.mean() / a.steps * 1e3, envt.mean() / a.steps * 1e3, (pol + envt).max(), (pol + envt).mean(), span,
                                              100.0 * (pol + envt).sum() / (span * 2048), env.stats()["rollout_aborts"]), flush=True)
+        if a.probe:
+            print("  policy phase split (us per env step): obs staging %.1f | learner policy trunk %.1f | opponent policy trunk %.1f | learner value trunk %.1f | heads + records %.1f"
+                  % tuple(st[:, 4 + q].mean() / 1e5 / a.steps * 1e3 for q in range(5)), flush=True)
     env.close()
