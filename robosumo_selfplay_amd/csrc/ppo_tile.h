@@ -60,7 +60,11 @@ static int x_stride(int D) {  // LDS row stride of the staged observation tile: 
 // ---------------------------------------------------------------------------------------------------------
 struct Net { const float PT_GAS *w0, *b0, *w1, *b1, *w2, *b2; int nout; };
 
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// Ordering point between LDS writes and reads of ONE wave (lanes exchanging a tile through the wave's own LDS region).  The
+// hardware executes a wave's LDS instructions in order, so only the compiler has to be held: a wavefront-scope fence.  (A
+// workgroup-scope fence also drains the vector-memory counter -- s_waitcnt vmcnt(0) -- i.e. it waits for every global store and
+// prefetch in flight, e.g. the rollout records written just before a policy trunk.)
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // forward of one trunk on the staged tile.  h1buf/h2buf [16][PT_HS] receive the relu activations; returns the head tile
 // (D layout: lane (i = lane&15, kq = lane>>4) holds rows 4kq+r, column i; columns >= nout are zero + garbage-free).
