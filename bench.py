@@ -85,7 +85,7 @@ def mfma_probe(torch, dev, learner, opponent, env, obs_b, ret_b, act_b, val_b, n
         # the calls are replayed from a HIP graph so that the GPU, not the Python enqueue loop, sets the pace
         eager = S["st"]
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with hostcfg.gc_paused(), torch.cuda.graph(graph):
             S["st"] = torch.cuda.current_stream(dev).cuda_stream
             for _ in range(reps):
                 call()

@@ -646,19 +646,33 @@ __global__ void __launch_bounds__(128) ppo_lstm_head_grad_kernel(ppo_lstm_net N,
                                                                  float* dlatent, float* dmean_o, float* dvalue_o, float* dlogstd_rows,
                                                                  double* stats) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  // (loops over the action dimensions are unrolled to MAXA with guards: with a runtime trip count the per-row arrays are indexed
+  // dynamically and live in scratch memory -- 1 500 cycles per unit of the latent)
   const int Hh = N.hidden, A = N.ac_dim;
+  // the head weights, staged once per workgroup: [unit][action dims | value]; read from global memory inside the unit loops every
+  // iteration waited for its own loads (the stores of the second loop keep the compiler from hoisting them)
+  __shared__ float wsh[LSTM_MAXH * (MAXA + 1)];
+  for (int e = threadIdx.x; e < Hh * (MAXA + 1); e += blockDim.x) {
+    const int kk = e / (MAXA + 1), q = e - kk * (MAXA + 1);
+    wsh[e] = q < A ? N.head_w[kk * A + q] : (q == MAXA ? N.vf_w[kk] : 0.0f);
+  }
+  __syncthreads();
   double s_pg = 0, s_vf = 0, s_kl = 0, s_cf = 0, s_n = 0;
   if (r < rows) {
     const float* L = latent + (size_t)r * Hh;
     float mean[MAXA], value = N.vf_b[0];
-    for (int q = 0; q < A; q++) mean[q] = N.head_b[q];
+#pragma unroll
+    for (int q = 0; q < MAXA; q++) mean[q] = q < A ? N.head_b[q] : 0.0f;
     for (int k = 0; k < Hh; k++) {
       const float lk = L[k];
-      value += lk * N.vf_w[k];
-      for (int q = 0; q < A; q++) mean[q] += lk * N.head_w[k * A + q];
+      const float* wk = wsh + k * (MAXA + 1);
+      value += lk * wk[MAXA];
+#pragma unroll
+      for (int q = 0; q < MAXA; q++) if (q < A) mean[q] += lk * wk[q];
     }
     float ss = 0, sum_logstd = 0, zq[MAXA], isd[MAXA];
-    for (int q = 0; q < A; q++) {
+#pragma unroll
+    for (int q = 0; q < MAXA; q++) if (q < A) {
       const float ls = N.logstd[q];
       isd[q] = expf(-ls);
       zq[q] = (actions[(size_t)r * A + q] - mean[q]) * isd[q];
@@ -679,7 +693,8 @@ __global__ void __launch_bounds__(128) ppo_lstm_head_grad_kernel(ppo_lstm_net N,
     s_pg = (double)(w * fmaxf(l1, l2)); s_vf = 0.5 * (double)(value - R) * (double)(value - R);
     s_kl = (double)(nlp - old); s_cf = fabsf(ratio - 1.0f) > cliprange ? 1.0 : 0.0; s_n = 1.0;
     float dm[MAXA];
-    for (int q = 0; q < A; q++) {
+#pragma unroll
+    for (int q = 0; q < MAXA; q++) if (q < A) {
       dm[q] = dnlp * (-(zq[q] * isd[q]));
       dmean_o[(size_t)r * A + q] = dm[q];
       dlogstd_rows[(size_t)r * A + q] = dnlp * (1.0f - zq[q] * zq[q]);
@@ -687,8 +702,10 @@ __global__ void __launch_bounds__(128) ppo_lstm_head_grad_kernel(ppo_lstm_net N,
     dvalue_o[r] = dv;
     float* dl = dlatent + (size_t)r * Hh;
     for (int k = 0; k < Hh; k++) {
-      float acc = dv * N.vf_w[k];
-      for (int q = 0; q < A; q++) acc += dm[q] * N.head_w[k * A + q];
+      const float* wk = wsh + k * (MAXA + 1);
+      float acc = dv * wk[MAXA];
+#pragma unroll
+      for (int q = 0; q < MAXA; q++) if (q < A) acc += dm[q] * wk[q];
       dl[k] = acc;
     }
   }

@@ -87,3 +87,22 @@ def apply(threads=None):
             pass
     _applied = threads
     return threads
+
+
+class gc_paused(object):
+    """Context manager for HIP graph capture: collect garbage now, then keep the cyclic collector off until the block ends.  A
+    collection that happens to run inside a capture may finalise device objects of an earlier model (its captured graphs, streams,
+    events); destroying those while a stream is capturing aborts the process."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False

@@ -15,7 +15,7 @@ import os
 
 import numpy as np
 
-from . import dist as sdist, policies, ppo_capi
+from . import dist as sdist, hostcfg, policies, ppo_capi
 
 
 class LstmSpec(object):
@@ -271,7 +271,7 @@ class LstmPPOModel(object):
                 t.cuda.current_stream(self.device).wait_stream(side)
                 t.cuda.synchronize(self.device)
                 graph = t.cuda.CUDAGraph()
-                with t.cuda.graph(graph):
+                with hostcfg.gc_paused(), t.cuda.graph(graph):
                     body()
                 ent = self._graphs[key] = dict(graph=graph, static=static)
             except Exception as e:                 # capture unsupported here: eager launches from now on

@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from . import dist as sdist, policies, ppo_capi
+from . import dist as sdist, hostcfg, policies, ppo_capi
 
 
 class PPOModel(object):
@@ -154,7 +154,7 @@ class PPOModel(object):
                 t.cuda.current_stream(self.device).wait_stream(side)
                 t.cuda.synchronize(self.device)
                 graph = t.cuda.CUDAGraph()
-                with t.cuda.graph(graph):
+                with hostcfg.gc_paused(), t.cuda.graph(graph):
                     cst = t.cuda.current_stream(self.device).cuda_stream
                     self._launch_loss_grad(obs, returns, actions, values, neglogpacs, weights, ent["idx"], n, cliprange, ent["adv"],
                                            ent["log_ratio"], cst)

@@ -57,3 +57,22 @@ def test_throttle_stats_parses_cpu_stat(monkeypatch):
     assert hostcfg.throttle_stats() == (3, 12345)
     monkeypatch.setattr(builtins, "open", _fake_open({"/sys/fs/cgroup/cpu.stat": None}))
     assert hostcfg.throttle_stats() is None
+
+
+def test_gc_paused_restores_collector_state():
+    import gc
+    from robosumo_selfplay_amd import hostcfg
+    assert gc.isenabled()
+    with hostcfg.gc_paused():
+        assert not gc.isenabled()
+        with hostcfg.gc_paused():                 # nested (a capture inside a paused region) keeps it off
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with hostcfg.gc_paused():
+            pass
+        assert not gc.isenabled()                 # was off before: stays off
+    finally:
+        gc.enable()
