@@ -22,8 +22,8 @@ NAMES = ["obs", "returns", "masks", "actions", "values", "neglogpacs", "rewards"
          "epinfos", "off_policy_ratio", "off_env_ratio", "total_ratio"]
 
 
-def _models(N, T, H, pool_k, seed):
-    spec = lstm_model.LstmSpec(121, 8, H)
+def _models(N, T, H, pool_k, seed, D=121, A=8):
+    spec = lstm_model.LstmSpec(D, A, H)
     np.random.seed(seed)
     learner = lstm_model.LstmPPOModel(policy=spec, nbatch_act=N, nsteps=T, trainable=False)
     rng = np.random.default_rng(seed)
@@ -43,9 +43,9 @@ def _models(N, T, H, pool_k, seed):
     return learner, opp
 
 
-def _run_pair(N, T, groups, pool_k, fused, H=128, chunk=0, seed=5):
-    env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=N, seed=21, groups=groups)
-    learner, opp = _models(N, T, H, pool_k, seed)
+def _run_pair(N, T, groups, pool_k, fused, H=128, chunk=0, seed=5, env_id="RoboSumo-Ant-vs-Ant-v0"):
+    env = SumoVecEnv(env_id, num_envs=N, seed=21, groups=groups)
+    learner, opp = _models(N, T, H, pool_k, seed, env.observation_space[0].shape[0], env.action_space[0].shape[0])
     r = Runner(env=env, models=[learner, opp], nsteps=T, nagent=2, gamma=0.995, lam=0.95, rho_bar=1.0, c_bar=1.0, anneal_bound=500)
     # (after the Runner's reset) a third of the envs continue close to the time limit: their episodes end -- done flags -> state
     # masks, auto-reset -- within the rollout
@@ -92,6 +92,15 @@ def test_fused_recurrent_rollout_matches_stepwise_path(N, T, groups, pool_k, chu
     outs = fused[0]
     assert outs[0][2].any() and len(outs[0][11]) > 0          # episodes ended inside the launch: masked states + auto-reset covered
     assert torch.isfinite(outs[1][4]).all() and fused[3]["diverged"] == 0
+
+
+@pytest.mark.parametrize("env_id", ["RoboSumo-Spider-vs-Spider-v0", "RoboSumo-Bug-vs-Bug-v0"])
+def test_fused_recurrent_rollout_other_scenes(env_id):
+    """The widest scene (Spider: 16 action dimensions = the whole head tile, one wave per SIMD kernel variant) and the Bug scene."""
+    fused = _run_pair(32, 7, 1, 2, True, env_id=env_id)
+    step = _run_pair(32, 7, 1, 2, False, env_id=env_id)
+    _assert_same(fused, step)
+    assert torch.isfinite(fused[0][1][4]).all() and fused[3]["diverged"] == 0
 
 
 def test_fused_recurrent_rollout_falls_back_for_other_widths():
