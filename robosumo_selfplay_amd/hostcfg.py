@@ -68,8 +68,13 @@ def apply(threads=None):
             _applied = 0
             return 0
     if threads is None:
-        # half the quota for pooled workers: the enqueueing thread, the HIP runtime's helper threads and the waiters need the rest
-        threads = max(1, cpu_quota() // 2)
+        # half the quota for pooled workers: the enqueueing thread, the HIP runtime's helper threads and the waiters need the rest;
+        # the ranks of one node (torchrun: LOCAL_WORLD_SIZE) share the job's cgroup, so each takes its share of that half
+        try:
+            ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        except ValueError:
+            ranks = 1
+        threads = max(1, cpu_quota() // (2 * ranks))
     for v in _VARS:
         os.environ.setdefault(v, str(threads))
     if "numpy" in sys.modules:                                  # pools created before us: narrow them in place

@@ -39,10 +39,20 @@ def test_apply_caps_pools_and_respects_overrides(monkeypatch):
     for v in hostcfg._VARS:
         monkeypatch.delenv(v, raising=False)
     monkeypatch.delenv("SUMO_HOST_THREADS", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     monkeypatch.setattr(hostcfg, "_applied", None)
     monkeypatch.setattr(hostcfg, "cpu_quota", lambda: 16)
     assert hostcfg.apply() == 8 and os.environ["OMP_NUM_THREADS"] == "8" and os.environ["OPENBLAS_NUM_THREADS"] == "8"
     assert hostcfg.apply() == 8                                           # idempotent
+    monkeypatch.setattr(hostcfg, "_applied", None)
+    for v in hostcfg._VARS:
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")                           # four ranks share the node's quota
+    assert hostcfg.apply() == 2 and os.environ["OPENBLAS_NUM_THREADS"] == "2"
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "64")
+    monkeypatch.setattr(hostcfg, "_applied", None)
+    assert hostcfg.apply() == 1                                           # never below one
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     monkeypatch.setattr(hostcfg, "_applied", None)
     monkeypatch.setenv("SUMO_HOST_THREADS", "0")
     assert hostcfg.apply() == 0                                           # opt-out
