@@ -16,6 +16,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef PT_PROBE          /* development hooks inside trunk_forward (the rollout kernel's probe build defines them) */
+#define PT_PROBE_INIT() do { } while (0)
+#define PT_PROBE(k) do { } while (0)
+#endif
+
 // Global-memory pointers.  A pointer the compiler cannot trace to a kernel argument (one read from a struct in memory: a net
 // description, the laundered launch arguments of the rollout kernel) is a GENERIC pointer and its loads are flat_load, which
 // occupy the LDS counter as well as the vector-memory counter: every wait for an LDS read then also waits for the weight loads in
@@ -86,6 +91,7 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
   for (int ct = 0; ct < 4; ct++) { bias0[ct] = net.b0[ct * 16 + i]; bias1[ct] = net.b1[ct * 16 + i]; }
   const bool col_ok = i < net.nout;
   const float bias2 = net.b2[col_ok ? i : 0];
+  PT_PROBE_INIT();
   // k-steps are issued eight at a time with all of their operand loads in flight first (32 weight loads per batch): the
   // accumulation order is unchanged, but one memory round trip is exposed per batch instead of one per k-step
   for (int k0 = 0; k0 < Dp; k0 += 32) {
@@ -107,6 +113,7 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
         for (int ct = 0; ct < 4; ct++) acc[ct] = PT_MFMA(a[u], b[u][ct], acc[ct]);
       }
   }
+  PT_PROBE(0);   // first layer: operand loads + products
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
     const float bias = bias0[ct];
@@ -118,6 +125,7 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
     acc[ct] = (f32x4){0, 0, 0, 0};
   }
   wave_sync();
+  PT_PROBE(1);   // bias + activation + LDS write of the first layer
   {
     float b[PT_H / 4][4];
 #pragma unroll
@@ -133,6 +141,7 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
       for (int ct = 0; ct < 4; ct++) acc[ct] = PT_MFMA(av[u], b[u][ct], acc[ct]);
     }
   }
+  PT_PROBE(2);   // second layer: loads + products
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
     const float bias = bias1[ct];
@@ -143,6 +152,7 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
     }
   }
   wave_sync();
+  PT_PROBE(3);   // bias + activation + LDS write of the second layer
   f32x4 out = (f32x4){0, 0, 0, 0};
   {
     float b[PT_H / 4], av[PT_H / 4];
@@ -153,6 +163,7 @@ __device__ __forceinline__ f32x4 trunk_forward(const Net& net, const float* xbuf
 #pragma unroll
     for (int u = 0; u < PT_H / 4; u++) out = PT_MFMA(av[u], b[u], out);
   }
+  PT_PROBE(4);   // head: loads + products
   float bias = col_ok ? bias2 : 0.0f;
 #pragma unroll
   for (int r = 0; r < 4; r++) out[r] += bias;

@@ -27,6 +27,11 @@
 #include "../../include/sumo_hip.h"
 #include "../../include/sumo_model.h"
 #include "../../include/sumo_ppo.h"   /* ppo_lstm_net: the recurrent nets of the fused rollout */
+#ifdef SUMO_POLICY_PROBE   /* development build: time inside the policy trunks, summed over all waves (sumo_debug_tprobe) */
+__device__ unsigned long long g_tprobe[8];
+#define PT_PROBE_INIT() unsigned long long tpl_ = __builtin_amdgcn_s_memrealtime()
+#define PT_PROBE(k) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_tprobe[k], t_ - tpl_); tpl_ = t_; } } while (0)
+#endif
 #include "ppo_tile.h"   /* MLP(64,64) trunk / Gaussian head on one MFMA tile: the policy phase of the fused rollout kernel */
 
 #define WAVE 64
@@ -3355,6 +3360,16 @@ extern "C" int sumo_rollout_steps_lstm(sumo_handle_t E, const sumo_rollout_lstm*
   return rollout_launch(E, r, 1, actions_dev, obs_dev, info_dev, done_dev, ep_r_dev, ep_dr_dev, ep_l_dev, stream);
 }
 
+#ifdef SUMO_POLICY_PROBE
+extern "C" int sumo_debug_tprobe(double* out8, int reset) {   // development: ticks (100 MHz) inside the five sections of trunk_forward
+  unsigned long long h[8];
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tprobe), sizeof h));
+  for (int k = 0; k < 8; k++) out8[k] = (double)h[k];
+  if (reset) { memset(h, 0, sizeof h); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tprobe), h, sizeof h)); }
+  return 0;
+}
+#endif
 extern "C" int sumo_debug_trace(sumo_handle_t E, uint64_t* stamps_dev) {
   if (!E) FAIL(-1, "bad handle");
   E->d_trace = (unsigned long long*)stamps_dev;

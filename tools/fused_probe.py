@@ -64,6 +64,16 @@ for cfg in a.configs.split(","):
               "of 2048 slots | aborts %d" % (pol.mean() / a.steps * 1e3, envt.mean() / a.steps * 1e3, (pol + envt).max(), (pol + envt).mean(), span,
                                              100.0 * (pol + envt).sum() / (span * 2048), env.stats()["rollout_aborts"]), flush=True)
         if a.probe:
+            import ctypes as C
+            from robosumo_selfplay_amd import capi
+            L = capi.lib()
+            buf = (C.c_double * 8)()
+            L.sumo_debug_tprobe(buf, 1)
+            run(); torch.cuda.synchronize()
+            L.sumo_debug_tprobe(buf, 1)
+            per = [buf[k] / 1e5 / (a.envs * a.steps * 3) * 1e3 for k in range(5)]      # us per trunk
+            print("  inside a trunk (us, mean of the three): layer-1 loads + products %.2f | bias / relu / LDS write %.2f | layer-2 %.2f | "
+                  "bias / relu / LDS write %.2f | head %.2f" % tuple(per), flush=True)
             print("  policy phase split (us per env step): obs staging %.1f | learner policy trunk %.1f | opponent policy trunk %.1f | learner value trunk %.1f | heads + records %.1f"
                   % tuple(st[:, 4 + q].mean() / 1e5 / a.steps * 1e3 for q in range(5)), flush=True)
     env.close()
