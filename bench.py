@@ -415,7 +415,8 @@ def main():
         def profile_json(name):
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                ok = ("<%d>" % model.nv) in pj["kernel"] and kernel_name in pj["kernel"] and pj["envs"] == env.group_size
+                kn = pj["kernel"]          # "sumo_step_kernel<28>" / "sumo_rollout_kernel<28, 0>" (nv, policy variant: 0 = the MLP one timed here)
+                ok = (("<%d>" % model.nv) in kn or ("<%d, 0>" % model.nv) in kn) and kernel_name in kn and pj["envs"] == env.group_size
                 return pj if ok else None
             except Exception:
                 return None
