@@ -114,6 +114,19 @@ typedef struct sumo_rollout_lstm {
 } sumo_rollout_lstm;
 int sumo_rollout_steps_lstm(sumo_handle_t h, const sumo_rollout_lstm* r, float* actions_dev, float* obs_dev, double* info_dev,
                             uint8_t* done_dev, double* ep_r_dev, double* ep_dr_dev, int32_t* ep_l_dev, void* stream);
+/* cfrc_mode (reference agents.py:190-214 reads sim.data.cfrc_ext into 84 of the 121 observation entries):
+ *   0 = zero (default): what the reference produces -- its MuJoCo 2.1 scenes declare no force / torque / accelerometer sensor, so
+ *       mj_rnePostConstraint never runs and cfrc_ext stays at its reset value 0;
+ *   1 = rne_post: the entries as a MuJoCo 2.1 with such a sensor would fill them: |clip(cfrc_ext, +-100)| with cfrc_ext = per-body sum
+ *       of the contact wrenches ([torque about the subtree CoM of the body's root ; force], world axes; -wrench on the contact's
+ *       first body, + on its second) of the forward evaluation that OPENS the last mj_step of the env step (sensors are evaluated
+ *       once per mj_step at its start state; the RK4 sub-stages skip them).  sumo_step then issues a second launch that re-derives
+ *       that state from the pre-step state (frame_skip - 1 sub-steps), so a step costs ~1.85x; sumo_rollout_steps* refuse the mode
+ *       (the policies read the observations inside their launch).  Envs whose episode ended in the step show the zeros of the reset
+ *       observation.  Parity: against the oracle's restatement of mj_rnePostConstraint (unpinned: no MuJoCo here).
+ * sumo_get_cfrc_ext: HOST float64 [E][nbody][6] of the last step (mode 1). */
+int sumo_set_cfrc_mode(sumo_handle_t h, int mode);
+int sumo_get_cfrc_ext(sumo_handle_t h, double* out);
 int sumo_get_state(sumo_handle_t h, double* qpos, double* qvel, double* warm, int32_t* counters /* [E][2] */);
 int sumo_set_state(sumo_handle_t h, const double* qpos, const double* qvel, const double* warm,
                    const int32_t* counters);

@@ -32,7 +32,7 @@ def lib():
         L.so_destroy.argtypes = [C.c_void_p]
         L.so_last_error.restype = C.c_char_p
         for name in ("so_dims", "so_reset", "so_step", "so_get_state", "so_set_state", "so_forward", "so_mj_step",
-                     "so_get_array", "so_stats", "so_set_maxcon", "so_set_jbcap", "so_set_seeds"):
+                     "so_get_array", "so_stats", "so_set_maxcon", "so_set_jbcap", "so_set_seeds", "so_set_cfrc_mode"):
             getattr(L, name).restype = C.c_int
         _LIB = L
     return _LIB
@@ -62,6 +62,11 @@ class OracleSim:
             assert self.L.so_set_maxcon(self.h, int(maxcon)) == 0
         if jbcap is not None:
             assert self.L.so_set_jbcap(self.h, int(jbcap)) == 0
+
+    def set_cfrc_mode(self, mode):
+        """'zero' (default: what the reference's MuJoCo 2.1 without force sensors yields) or 'rne_post' (cfrc_ext as
+        mj_rnePostConstraint fills it at the start of the last mj_step of an env step)."""
+        assert self.L.so_set_cfrc_mode(self.h, {"zero": 0, "rne_post": 1}[mode]) == 0
 
     def __del__(self):
         try:

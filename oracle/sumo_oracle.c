@@ -54,12 +54,14 @@ typedef struct {
   double *Ma, *grad, *Mgrad, *search, *Mv, *Jv, *H, *tmpv;
   double *rkX[4], *rkF[4], *rkdX;
   long n_forward, n_newton, n_contacts, n_efc, max_ncon, max_nefc, max_newton, n_diverged;
+  double* cfrc_ext;   /* [nbody][6] (cfrc_mode = rne_post): contact wrenches about the root's subtree CoM, world axes, [torque ; force] */
 } env_t;
 
 struct so_sim {
   void* blob;
   sumo_model_t m;
   int N, maxcon, jbcap, maxefc, obs_stride, act_stride;
+  int cfrc_mode;      /* 0: cfrc_ext == 0 (the reference's MuJoCo 2.1 without force sensors); 1: as mj_rnePostConstraint fills it */
   env_t* env;
 };
 
@@ -894,6 +896,38 @@ static void integrate_pos(const sumo_model_t* m, double* qpos, const double* vel
   }
 }
 
+/* cfrc_ext as mj_rnePostConstraint leaves it (the contact part: no xfrc_applied here), SURVEY.md App. A.9/A.10: for every contact
+ * the force in the contact frame is decoded from its four pyramid rows (mju_decodePyramid: normal = sum of the edge forces,
+ * tangent k = mu (f_2k - f_2k+1)), rotated to world axes and applied at the contact point: -wrench to body1, +wrench to body2,
+ * each as [torque about the subtree CoM of the body's root ; force].  With force sensors in the model MuJoCo 2.1 evaluates this in
+ * mj_forward -- once per mj_step, at the step's START state (the RK4 sub-stages skip sensors) -- so after frame_skip steps the data
+ * hold the forces of the evaluation that opened the last step. */
+static void rne_post(const so_sim* s, env_t* d) {
+  const sumo_model_t* m = &s->m;
+  const int* gbody = SUMO_I(m, geom_bodyid);
+  const int* rootid = SUMO_I(m, body_rootid);
+  memset(d->cfrc_ext, 0, (size_t)6 * m->nbody * sizeof(double));
+  int r0 = 0;
+  while (r0 < d->nefc && d->etype[r0] == 0) r0++;             /* limit rows come first */
+  for (int ci = 0; ci < d->ncon; ci++, r0 += 4) {
+    if (r0 + 4 > d->nefc) break;                              /* rows cut off by maxefc carry no force */
+    const contact_t* c = d->con + ci;
+    const double* f = d->eforce + r0;
+    const double fc[3] = {f[0] + f[1] + f[2] + f[3], c->mu * (f[0] - f[1]), c->mu * (f[2] - f[3])};
+    double F[3];
+    for (int k = 0; k < 3; k++) F[k] = c->frame[k] * fc[0] + c->frame[3 + k] * fc[1] + c->frame[6 + k] * fc[2];
+    for (int side = 0; side < 2; side++) {
+      const int b = gbody[side ? c->g2 : c->g1];
+      if (b == 0) continue;                                   /* the world body's entry is observed by nobody: not computed */
+      const double sg = side ? 1.0 : -1.0;
+      double arm[3], tq[3];
+      for (int k = 0; k < 3; k++) arm[k] = c->pos[k] - d->subtree_com[3 * rootid[b] + k];
+      cross3(tq, arm, F);
+      for (int k = 0; k < 3; k++) { d->cfrc_ext[6 * b + k] += sg * tq[k]; d->cfrc_ext[6 * b + 3 + k] += sg * F[k]; }
+    }
+  }
+}
+
 static void mj_step(const so_sim* s, env_t* d) {
   static const double A[3] = {0.5, 0.5, 1.0};
   static const double B[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
@@ -901,6 +935,7 @@ static void mj_step(const so_sim* s, env_t* d) {
   int nq = m->nq, nv = m->nv;
   double h = SUMO_F(m, opt)[SUMO_OPT_TIMESTEP];
   forward(s, d);
+  if (s->cfrc_mode) rne_post(s, d);
   memcpy(d->rkX[0], d->qpos, nq * sizeof(double));
   memcpy(d->rkX[0] + nq, d->qvel, nv * sizeof(double));
   memcpy(d->rkF[0], d->qacc, nv * sizeof(double));
@@ -957,9 +992,17 @@ static void write_obs(const so_sim* s, const env_t* d, float* obs) {
     int o_ = 1 - a, k = 0;
     for (int i = 0; i < anq[a]; i++) o[k++] = (float)d->qpos[aq[a] + i];
     for (int i = 0; i < anv[a]; i++) o[k++] = (float)d->qvel[ad[a] + i];
-    for (int i = 0; i < 6 * anb[a]; i++) o[k++] = 0.0f;
+    /* |clip(cfrc_ext, +-CFRC_CLIP)| of the own bodies and of the opponent's torso (agents.py:13,192-208); zeros in the default mode */
+    const int* ab = SUMO_I(m, agent_bodyadr);
+    for (int i = 0; i < 6 * anb[a]; i++) {
+      double v = s->cfrc_mode ? d->cfrc_ext[6 * ab[a] + i] : 0.0;
+      o[k++] = (float)fabs(v > 100.0 ? 100.0 : (v < -100.0 ? -100.0 : v));
+    }
     for (int i = 0; i < 7; i++) o[k++] = (float)d->qpos[aq[o_] + i];
-    for (int i = 0; i < 6; i++) o[k++] = 0.0f;
+    for (int i = 0; i < 6; i++) {
+      double v = s->cfrc_mode ? d->cfrc_ext[6 * ab[o_] + i] : 0.0;
+      o[k++] = (float)fabs(v > 100.0 ? 100.0 : (v < -100.0 ? -100.0 : v));
+    }
     o[k++] = (float)(-1.0 + 2.0 * d->num_steps / 500.0);
     for (; k < s->obs_stride; k++) o[k] = 0.0f;
   }
@@ -973,6 +1016,7 @@ static void reset_env(const so_sim* s, env_t* d) {
   memcpy(d->qpos, SUMO_F(m, qpos0), nq * sizeof(double)); /* mj_resetData */
   memset(d->qvel, 0, nv * sizeof(double));
   memset(d->warm, 0, nv * sizeof(double));
+  memset(d->cfrc_ext, 0, (size_t)6 * m->nbody * sizeof(double));   /* mj_resetData; the reset observation shows zeros */
   double phi = 2.0 * PI * rng_uniform(d->seed, rc, 0);
   for (int a = 0; a < 2; a++) {
     double ang = phi + a * (2.0 * PI / 2.0);
@@ -1127,7 +1171,7 @@ so_sim* so_create(const void* blob, size_t nbytes, int num_envs) {
     d->ximat = dalloc(9 * nb); d->xanchor = dalloc(3 * nj); d->xaxis = dalloc(3 * nj); d->gxpos = dalloc(3 * ng);
     d->gxmat = dalloc(9 * ng); d->subtree_com = dalloc(3 * nb); d->cinert = dalloc(10 * nb); d->crb = dalloc(10 * nb);
     d->cdof = dalloc(6 * nv); d->cdof_dot = dalloc(6 * nv); d->cvel = dalloc(6 * nb); d->cacc = dalloc(6 * nb);
-    d->cfrc = dalloc(6 * nb); d->M = dalloc(nv * nv); d->L = dalloc(nv * nv); d->qfrc_bias = dalloc(nv);
+    d->cfrc = dalloc(6 * nb); d->cfrc_ext = dalloc(6 * nb); d->M = dalloc(nv * nv); d->L = dalloc(nv * nv); d->qfrc_bias = dalloc(nv);
     d->qfrc_passive = dalloc(nv); d->qfrc_act = dalloc(nv); d->qfrc_smooth = dalloc(nv); d->qacc_smooth = dalloc(nv);
     d->qacc = dalloc(nv); d->qfrc_constraint = dalloc(nv);
     d->con = (contact_t*)calloc(MAXCON_CAP, sizeof(contact_t));
@@ -1154,7 +1198,7 @@ void so_destroy(so_sim* s) {
                       d->cacc, d->cfrc, d->M, d->L, d->qfrc_bias, d->qfrc_passive, d->qfrc_act, d->qfrc_smooth,
                       d->qacc_smooth, d->qacc, d->qfrc_constraint, d->J, d->epos, d->emargin, d->ediag, d->eR, d->eD,
                       d->eK, d->eB, d->eimp, d->evel, d->earef, d->ejar, d->eforce, d->Ma, d->grad, d->Mgrad,
-                      d->search, d->Mv, d->Jv, d->H, d->tmpv, d->rkX[0], d->rkX[1], d->rkX[2], d->rkX[3], d->rkF[0],
+                      d->search, d->Mv, d->Jv, d->H, d->tmpv, d->cfrc_ext, d->rkX[0], d->rkX[1], d->rkX[2], d->rkX[3], d->rkF[0],
                       d->rkF[1], d->rkF[2], d->rkF[3], d->rkdX};
     for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; i++) free(ptrs[i]);
     free(d->con); free(d->etype);
@@ -1172,6 +1216,11 @@ int so_dims(const so_sim* s, int* o) {
 int so_set_jbcap(so_sim* s, int jbcap) {
   if (jbcap < 0) return -1;
   s->jbcap = jbcap;
+  return 0;
+}
+int so_set_cfrc_mode(so_sim* s, int mode) {
+  if (mode != 0 && mode != 1) return -1;
+  s->cfrc_mode = mode;
   return 0;
 }
 int so_set_maxcon(so_sim* s, int maxcon) {
@@ -1235,6 +1284,7 @@ int so_forward(so_sim* s, int e, const double* ctrl) {
   env_t* d = s->env + e;
   if (ctrl) memcpy(d->ctrl, ctrl, s->m.nu * sizeof(double));
   forward(s, d);
+  if (s->cfrc_mode) rne_post(s, d);
   return 0;
 }
 int so_mj_step(so_sim* s, int e, const double* ctrl, int n) {
@@ -1255,7 +1305,7 @@ int so_get_array(so_sim* s, int e, const char* name, double* out, int cap) {
   ARR("xquat", d->xquat, 4 * nb) ARR("xipos", d->xipos, 3 * nb) ARR("gxpos", d->gxpos, 3 * m->ngeom)
   ARR("subtree_com", d->subtree_com, 3 * nb) ARR("qfrc_constraint", d->qfrc_constraint, nv)
   ARR("qfrc_smooth", d->qfrc_smooth, nv) ARR("cvel", d->cvel, 6 * nb) ARR("efc_J", d->J, d->nefc * nv)
-  ARR("efc_force", d->eforce, d->nefc) ARR("efc_aref", d->earef, d->nefc) ARR("efc_R", d->eR, d->nefc)
+  ARR("cfrc_ext", d->cfrc_ext, 6 * s->m.nbody) ARR("efc_force", d->eforce, d->nefc) ARR("efc_aref", d->earef, d->nefc) ARR("efc_R", d->eR, d->nefc)
   ARR("efc_pos", d->epos, d->nefc) ARR("efc_jar", d->ejar, d->nefc)
 #undef ARR
   if (!strcmp(name, "contacts")) { /* per contact: dist, pos3, normal3, g1, g2 */

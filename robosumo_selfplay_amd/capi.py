@@ -58,6 +58,8 @@ def lib():
         L.sumo_rollout_steps.argtypes = [vp, C.POINTER(Rollout)] + [vp] * 8
         L.sumo_rollout_steps_lstm.argtypes = [vp, C.POINTER(RolloutLstm)] + [vp] * 8
         L.sumo_get_state.argtypes = [vp] * 5
+        L.sumo_set_cfrc_mode.argtypes = [vp, i32]
+        L.sumo_get_cfrc_ext.argtypes = [vp, vp]
         L.sumo_set_state.argtypes = [vp] * 5
         L.sumo_debug_forward.argtypes = [vp] * 4
         L.sumo_stats.argtypes = [vp, vp]
@@ -66,14 +68,14 @@ def lib():
         L.sumo_debug_trace.restype = i32
         L.sumo_profile.restype = i32
         for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps", "sumo_rollout_steps_lstm", "sumo_get_state",
-                  "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
+                  "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
             getattr(L, n).restype = i32
         _LIB = L
     return _LIB
 
 
 EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps",
-           "sumo_rollout_steps_lstm", "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace")
+           "sumo_rollout_steps_lstm", "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace")
 
 
 def _np(a):
@@ -128,6 +130,15 @@ class Engine:
     def rollout_steps_lstm(self, ro, actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream=None):
         """The same for recurrent policies (``sumo_rollout_steps_lstm``); ``ro`` is a filled :class:`RolloutLstm`."""
         _chk(lib().sumo_rollout_steps_lstm(self.h, C.byref(ro), actions_ptr, obs_ptr, info_ptr, done_ptr, ep_r_ptr, ep_dr_ptr, ep_l_ptr, stream))
+
+    def set_cfrc_mode(self, mode):
+        """'zero' (default, the reference's behaviour) or 'rne_post' (include/sumo_hip.h: cfrc_mode)."""
+        _chk(lib().sumo_set_cfrc_mode(self.h, {"zero": 0, "rne_post": 1}[mode]))
+
+    def get_cfrc_ext(self):
+        out = np.zeros((self.N, self.nbody, 6))
+        _chk(lib().sumo_get_cfrc_ext(self.h, _np(out)))
+        return out
 
     def get_state(self):
         qpos = np.zeros((self.N, self.nq))

@@ -2222,6 +2222,97 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// cfrc_mode = rne_post: the contact-force entries of the observations as a MuJoCo 2.1 WITH force sensors
+// would show them.  The reference's scenes have no such sensor, so its cfrc_ext is zero and `zero` is the default (and what
+// sumo_step writes); this optional second launch fills the entries in afterwards and costs most of another env step: it
+// repeats the first frame_skip - 1 sub-steps from the pre-step state (saved by the host before sumo_step) to reach the state
+// the LAST mj_step started from -- mj_forward evaluates sensors, hence mj_rnePostConstraint, once per mj_step at its start
+// state; the RK4 sub-stages skip them -- evaluates forward() there, turns the solution into the pyramid-row forces
+// f = -D min(J qacc - aref, 0), recomputes the contact geometry (the records shared the mass matrix's storage) and sums,
+// per body, -wrench (body 1) / +wrench (body 2) about the subtree CoM of the body's agent: [torque ; force], world axes.
+// The hot kernels are untouched by this mode.  Envs whose episode ended in the step keep the zeros of their reset observation.
+// ---------------------------------------------------------------------------------------------------------
+struct CfrcArgs {
+  const double* prev_state;   // [N][state_stride]: the state before the step
+  double* fbuf;               // [N][5 * maxcon] scratch: row forces | friction coefficients
+  double* cfrc_out;           // [N][nbody][6] or NULL (tests)
+};
+
+template <int NV>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE_OF(NV), SUMO_WPE_OF(NV))))
+sumo_cfrc_kernel(const Params* P, StepArgs a, CfrcArgs q) {
+  Ctx<NV> c;
+  ctx_init(c, P, smem_dyn);
+  const sumo_model_t& mdl = P->mdl;
+  const int e = blockIdx.x, lane = c.lane, nb = mdl.nbody;
+  if (e >= a.N) return;
+  if (q.cfrc_out) for (int i = lane; i < 6 * nb; i += WAVE) q.cfrc_out[(size_t)e * 6 * nb + i] = 0.0;
+  if (a.done[2 * e]) return;
+  StepArgs ap = a;
+  ap.state = const_cast<double*>(q.prev_state);
+  load_state(c, ap, e);
+  if (lane < mdl.nu) {
+    const float PT_GAS* act0 = pt_global(a.actions) + (size_t)e * 2 * a.act_stride;
+    const int ag = lane >= MI(agent_uadr)[1] ? 1 : 0;
+    S(ctrl)[lane] = (double)act0[ag * a.act_stride + (lane - MI(agent_uadr)[ag])];
+  }
+  SYNC();
+  if (state_is_bad(c)) return;
+  if (mdl.frame_skip > 1) mj_steps(c, mdl.frame_skip - 1);
+  c.use_prev = 0;
+  forward(c);
+  // pyramid-row forces of the solution (x = qacc): rows 4 ci + k of contact ci; limit rows carry no external force
+  const int ncon = c.ncon, maxcon = c.L.maxcon;
+  double* fb = q.fbuf + (size_t)e * 5 * maxcon;
+  contact_Jx(c, S(x));
+  for (int r = lane; r < 4 * ncon; r += WAVE) {
+    const double jar = row_Jx(c, r) - S(aref)[r];
+    fb[r] = jar < 0 ? -S(D)[r >> 2] * jar : 0.0;
+  }
+  for (int ci = lane; ci < ncon; ci += WAVE) fb[4 * maxcon + ci] = S(cpar)[ci];
+  __threadfence();
+  SYNC();
+  // contact points / frames / bodies again (same state, same order), subtree CoMs
+  position_velocity(c);
+  collision(c);
+  const int nc2 = c.ncon < ncon ? c.ncon : ncon;   // (make_constraint may have cut the list to the Jacobian pool)
+  KCONSTS();
+  double w[6] = {0, 0, 0, 0, 0, 0};
+  const int b = lane, ag = K.b_agent;
+  if (b > 0 && b < nb) {
+    const double* com = S(com) + 3 * ag;
+    for (int ci = 0; ci < nc2; ci++) {
+      const int* cb = c.si + c.L.con_b + 4 * ci;
+      const int side = cb[1] == b ? 1 : (cb[0] == b ? 0 : -1);
+      if (side < 0) continue;
+      const double* cd = S(cond) + 14 * ci;
+      const double f0 = fb[4 * ci], f1 = fb[4 * ci + 1], f2 = fb[4 * ci + 2], f3 = fb[4 * ci + 3], mu = fb[4 * maxcon + ci];
+      const double fc[3] = {(f0 + f1) + (f2 + f3), mu * (f0 - f1), mu * (f2 - f3)};
+      double F[3], arm[3], tq[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) { F[k] = cd[4 + k] * fc[0] + cd[7 + k] * fc[1] + cd[10 + k] * fc[2]; arm[k] = cd[1 + k] - com[k]; }
+      cross3(tq, arm, F);
+      const double sg = side ? 1.0 : -1.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { w[k] += sg * tq[k]; w[3 + k] += sg * F[k]; }
+    }
+    if (q.cfrc_out)
+      for (int k = 0; k < 6; k++) q.cfrc_out[((size_t)e * nb + b) * 6 + k] = w[k];
+    // agents.py:192-208: |clip(cfrc_ext, +-100)| of the own bodies, then (for the other side) of this agent's torso
+    const int i0 = MI(agent_bodyadr)[ag], o = 1 - ag;
+    float* ob = a.obs + (size_t)e * 2 * a.obs_stride;
+    float* own = ob + ag * a.obs_stride + MI(agent_nq)[ag] + MI(agent_nv)[ag] + 6 * (b - i0);
+#pragma unroll
+    for (int k = 0; k < 6; k++) own[k] = (float)fabs(fmin(fmax(w[k], -100.0), 100.0));
+    if (b == i0) {
+      float* opp = ob + o * a.obs_stride + MI(agent_nq)[o] + MI(agent_nv)[o] + 6 * MI(agent_nbody)[o] + 7;
+#pragma unroll
+      for (int k = 0; k < 6; k++) opp[k] = (float)fabs(fmin(fmax(w[k], -100.0), 100.0));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Fused rollout: K consecutive self-play rollout steps of an env in ONE launch (reference runner.py:62-151 for MLP(64,64)
 // policies).  The wave that owns env e evaluates the five policy / value passes of a step itself -- the env's two
 // observations are rows 0 and 1 of an MFMA tile, the three trunks (learner policy, opponent policy, learner value) run through
@@ -2615,6 +2706,8 @@ struct sumo_engine {
   double* d_af = nullptr;
   signed char* d_pic = nullptr;
   double* d_state = nullptr;
+  int cfrc_mode = 0;                       // 0 zero (reference behaviour), 1 rne_post (sumo_set_cfrc_mode)
+  double *d_state_prev = nullptr, *d_fbuf = nullptr, *d_cfrc = nullptr;   // rne_post: pre-step state, row-force scratch, cfrc_ext [N][nbody][6]
   int* d_counters = nullptr;
   uint64_t* d_seeds = nullptr;
   unsigned long long* d_stats = nullptr;
@@ -3158,7 +3251,7 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
 extern "C" int sumo_destroy(sumo_handle_t E) {
   if (!E) return 0;
   (void)hipSetDevice(E->device);
-  (void)hipFree(E->d_params); (void)hipFree(E->d_lanes); (void)hipFree(E->d_pair_rec); (void)hipFree(E->d_pair_bound); (void)hipFree(E->d_blob); (void)hipFree(E->d_ai); (void)hipFree(E->d_af); (void)hipFree(E->d_pic); (void)hipFree(E->d_state);
+  (void)hipFree(E->d_params); (void)hipFree(E->d_lanes); (void)hipFree(E->d_pair_rec); (void)hipFree(E->d_pair_bound); (void)hipFree(E->d_blob); (void)hipFree(E->d_ai); (void)hipFree(E->d_af); (void)hipFree(E->d_pic); (void)hipFree(E->d_state); (void)hipFree(E->d_state_prev); (void)hipFree(E->d_fbuf); (void)hipFree(E->d_cfrc);
   (void)hipFree(E->d_counters); (void)hipFree(E->d_seeds); (void)hipFree(E->d_stats); (void)hipFree(E->d_rsched);
   (void)hipFree(E->d_cost); (void)hipFree(E->d_cost_sorted); (void)hipFree(E->d_iota); (void)hipFree(E->d_perm); (void)hipFree(E->d_sort_tmp);
   delete E;
@@ -3245,8 +3338,24 @@ extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_d
   } else if (E->sched) {
     a.cost = E->d_cost; a.perm = E->perm_valid ? E->d_perm : nullptr;
   }
+  if (E->cfrc_mode)   // rne_post: the state this step starts from, for the second launch below
+    HIPCHK(hipMemcpyAsync(E->d_state_prev, E->d_state, (size_t)E->N * E->state_stride * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   SUMO_DISPATCH_N(sumo_step_kernel, E, (hipStream_t)stream, a, nblocks);
   HIPCHK(hipGetLastError());
+  if (E->cfrc_mode) {
+    CfrcArgs q;
+    q.prev_state = E->d_state_prev; q.fbuf = E->d_fbuf; q.cfrc_out = E->d_cfrc;
+    StepArgs ac = base_args(E);
+    ac.actions = actions_dev; ac.obs = obs_dev; ac.done = done_dev;
+    dim3 g_(E->N), b_(WAVE);
+    size_t lds_ = (size_t)E->L.total_bytes;
+    hipStream_t st_ = (hipStream_t)stream;
+    if (!for_kernel_variant(E->hm.nv, [&](auto nvc_) {
+          hipLaunchKernelGGL(sumo_cfrc_kernel<decltype(nvc_)::value>, g_, b_, lds_, st_, E->d_params, ac, q);
+        }))
+      FAIL(-19, "no kernel variant for nv=%d", E->hm.nv);
+    HIPCHK(hipGetLastError());
+  }
   if (E->sched && E->N > SCHED_RANK_MAX) {   // costs stay below 2^16 (see the step kernel's epilogue)
     HIPCHK(rocprim::radix_sort_pairs_desc(E->d_sort_tmp, E->sort_tmp_bytes, E->d_cost, E->d_cost_sorted, E->d_iota, E->d_perm,
                                           (size_t)E->N, 0, 16, (hipStream_t)stream));
@@ -3293,6 +3402,7 @@ static int rollout_launch(sumo_engine* E, const RolloutArgs& r, int policy, floa
 // scene checks shared by the two entry points; returns the observation / action width through od / ad
 static int rollout_scene(sumo_engine* E, int T, int Ntot, int env_offset, int s0, int K, int* od, int* ad) {
   const sumo_model_t* m = &E->hm;
+  if (E->cfrc_mode) FAIL(-12, "cfrc_mode rne_post fills the observations in a second launch per step: use sumo_step (the fused rollout evaluates the policies inside its launch)");
   const int* anq = SUMO_I(m, agent_nq); const int* anv = SUMO_I(m, agent_nv); const int* anb = SUMO_I(m, agent_nbody);
   const int* anu = SUMO_I(m, agent_nu);
   const int od0 = anq[0] + anv[0] + 6 * anb[0] + 14, od1 = anq[1] + anv[1] + 6 * anb[1] + 14;
@@ -3370,6 +3480,27 @@ extern "C" int sumo_debug_tprobe(double* out8, int reset) {   // development: ti
   return 0;
 }
 #endif
+extern "C" int sumo_set_cfrc_mode(sumo_handle_t E, int mode) {
+  if (!E) FAIL(-1, "bad handle");
+  if (mode != 0 && mode != 1) FAIL(-2, "cfrc_mode %d: 0 (zero) or 1 (rne_post)", mode);
+  HIPCHK(hipSetDevice(E->device));
+  if (mode && !E->d_state_prev) {
+    HIPCHK(hipMalloc((void**)&E->d_state_prev, (size_t)E->N * E->state_stride * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&E->d_fbuf, (size_t)E->N * 5 * E->L.maxcon * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&E->d_cfrc, (size_t)E->N * 6 * E->hm.nbody * sizeof(double)));
+    HIPCHK(hipMemset(E->d_cfrc, 0, (size_t)E->N * 6 * E->hm.nbody * sizeof(double)));
+  }
+  E->cfrc_mode = mode;
+  return 0;
+}
+extern "C" int sumo_get_cfrc_ext(sumo_handle_t E, double* out) {   // HOST float64 [E][nbody][6] of the last step (rne_post mode)
+  if (!E || !out) FAIL(-1, "bad arguments");
+  if (!E->d_cfrc) FAIL(-2, "cfrc_mode is zero: nothing was computed");
+  HIPCHK(hipSetDevice(E->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, E->d_cfrc, (size_t)E->N * 6 * E->hm.nbody * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
 extern "C" int sumo_debug_trace(sumo_handle_t E, uint64_t* stamps_dev) {
   if (!E) FAIL(-1, "bad handle");
   E->d_trace = (unsigned long long*)stamps_dev;

@@ -210,6 +210,8 @@ class Runner(AbstractEnvRunner):
         env = self.env
         if not (self.device_mode and self.fused_rollout and self.recurrent and hasattr(env, "rollout_steps_lstm_group")):
             return False
+        if getattr(env, "cfrc_mode", "zero") != "zero":      # the force entries are filled in by a second launch per step
+            return False
         m0, m1 = self.models[0], self.models[1]
         if type(m0) is not LstmPPOModel or type(m1) not in (LstmPPOModel, LstmOpponentPool):
             return False
@@ -257,6 +259,8 @@ class Runner(AbstractEnvRunner):
     def fused_ok(self):
         """The fused rollout launch applies to device mode with two plain MLP policies of the env's own observation / action shape."""
         if not (self.device_mode and self.fused_rollout and not self.recurrent and hasattr(self.env, "rollout_steps_group")):
+            return False
+        if getattr(self.env, "cfrc_mode", "zero") != "zero":
             return False
         m0, m1 = self.models[0], self.models[1]
         if not (hasattr(m0, "act_model") and hasattr(m1, "act_model")):

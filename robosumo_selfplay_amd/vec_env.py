@@ -63,7 +63,8 @@ class EnvSpec(object):
 
 
 class SumoVecEnv(VecEnv):
-    def __init__(self, env_id="RoboSumo-Ant-vs-Ant-v0", num_envs=1, seed=0, device=0, asset_dir=None, model=None, groups=1):
+    def __init__(self, env_id="RoboSumo-Ant-vs-Ant-v0", num_envs=1, seed=0, device=0, asset_dir=None, model=None, groups=1,
+                 cfrc_mode="zero"):
         """``groups`` > 1 splits the envs into that many equal, contiguous groups, each with its own engine: a group's step is
         its own kernel launch (``step_device_group``), so a caller that advances the groups on separate streams is not held
         back by the slowest env of the whole batch at every step (the device-mode Runner does that).  All buffers stay
@@ -79,6 +80,14 @@ class SumoVecEnv(VecEnv):
             raise ValueError("num_envs %d is not divisible into %d groups" % (num_envs, groups))
         self.groups, self.group_size = groups, num_envs // groups
         self.engines = [capi.Engine(self.model, self.group_size, device=int(device)) for _ in range(groups)]
+        # 'zero' = the reference's observations (its MuJoCo 2.1 scenes carry no force sensor: cfrc_ext == 0); 'rne_post' fills the contact-force
+        # entries as a sensor-equipped MuJoCo would (second launch per step, no fused rollout; include/sumo_hip.h: cfrc_mode)
+        if cfrc_mode not in ("zero", "rne_post"):
+            raise ValueError("cfrc_mode must be 'zero' or 'rne_post'")
+        self.cfrc_mode = cfrc_mode
+        if cfrc_mode != "zero":
+            for E_ in self.engines:
+                E_.set_cfrc_mode(cfrc_mode)
         self.engine = self.engines[0]                                   # dimensions / limits (identical for every group)
         E = self.engine
         obs_dims, act_dims = self.model.obs_dims, self.model.act_dims

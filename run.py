@@ -39,6 +39,8 @@ def main(argv):
     ap.add_argument("--suffix", default="0")
     ap.add_argument("--env_groups", type=int, default=0, help="env groups per GPU (vec_env.SumoVecEnv): 0 = 1 when the whole rollout is one fused "
                     "launch that balances the envs itself (MLP policies, LSTM policies with nlstm 128), 2 for step-by-step launches on two streams")
+    ap.add_argument("--cfrc_mode", default="zero", choices=["zero", "rne_post"], help="contact-force observation entries: zero = the reference's "
+                    "behaviour (MuJoCo 2.1 without force sensors), rne_post = as mj_rnePostConstraint would fill them (second launch per step)")
     args, unknown = ap.parse_known_args(argv)
     extra = parse_unknown(unknown)
     from robosumo_selfplay_amd import alg_ppo, defaults, dist as sdist
@@ -51,12 +53,13 @@ def main(argv):
         os.makedirs(log_path, exist_ok=True)
     start, per = sdist.shard_envs(args.num_env, rank, world)
     if args.env_groups <= 0:
-        stepwise = os.environ.get("SUMO_FUSED_ROLLOUT", "1") == "0" or (args.network == "lstm" and int(extra.get("nlstm", 128)) != 128)
+        stepwise = (os.environ.get("SUMO_FUSED_ROLLOUT", "1") == "0" or args.cfrc_mode != "zero"
+                    or (args.network == "lstm" and int(extra.get("nlstm", 128)) != 128))
         args.env_groups = 2 if stepwise else 1
     groups = args.env_groups if per % max(1, args.env_groups) == 0 else 1
     import torch
     local_rank = local_rank % max(1, torch.cuda.device_count())        # gloo rehearsal of N ranks on fewer GPUs
-    env = make_vec_env(args.env, per, args.seed + start, device=local_rank, groups=groups)  # run.py:144: env i gets seed + i
+    env = make_vec_env(args.env, per, args.seed + start, device=local_rank, groups=groups, cfrc_mode=args.cfrc_mode)  # run.py:144: env i gets seed + i
     kw = defaults.get_default_params(args.env, args.algo)
     kw.update(extra)
     if args.network == "lstm":       # the RoboSumo defaults describe the MLP (defaults.py:8-26); recurrent nets share the latent

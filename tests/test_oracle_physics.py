@@ -686,3 +686,50 @@ def test_capsule_on_tatami_contacts_match_geometry(ant_model, oracle_lib):
             assert max(abs(p[0]), abs(p[1])) <= m.geom_size[1][0] + 1e-9    # on the top face
             seen += 1
     assert seen >= 40, seen
+
+
+def test_oracle_cfrc_ext_against_generalised_constraint_force():
+    """cfrc_mode = rne_post in the oracle (rne_post(): the restatement of mj_rnePostConstraint's contact part) against an independent
+    route through the same solution: the per-body contact wrenches of an agent, summed, must be the generalised constraint force
+    J^T f on that agent's free joint -- force on its three translational dofs (world axes), torque about the torso's origin on its
+    three rotational dofs (body axes) -- because joint-limit rows only act on hinge dofs.  Also: resting weight, and the default
+    mode's zeros in the observation."""
+    from robosumo_selfplay_amd import mjcf
+    from oracle.oracle import OracleSim
+    m = mjcf.load_model("RoboSumo-Ant-vs-Ant-v0")
+    sim = OracleSim(m, 6)
+    obs0 = sim.reset(seeds=np.arange(6, dtype=np.uint64) + 40)
+    rng = np.random.default_rng(8)
+    nb = sim.nbody
+    out = None
+    for t in range(3):
+        out = sim.step((rng.standard_normal((6, 2, sim.act_stride)) * 0.6).astype(np.float32))
+    assert np.all(out[0][:, :, 29:107] == 0) and np.all(out[0][:, :, 114:120] == 0)          # default: cfrc_ext == 0 (agents.py:190-214 on MuJoCo 2.1)
+    sim.set_cfrc_mode("rne_post")
+    checked = 0
+    for t in range(25):
+        out = sim.step((rng.standard_normal((6, 2, sim.act_stride)) * 0.6).astype(np.float32))
+        for e in range(6):
+            sim.forward(e)
+            cf = sim.array("cfrc_ext", e).reshape(nb, 6)
+            qc = sim.array("qfrc_constraint", e)
+            com = sim.array("subtree_com", e).reshape(nb, 3)
+            xpos = sim.array("xpos", e).reshape(nb, 3)
+            xquat = sim.array("xquat", e).reshape(nb, 4)
+            for ag in range(2):
+                b0, n, d0 = int(m.agent_bodyadr[ag]), int(m.agent_nbody[ag]), int(m.agent_dofadr[ag])
+                F = cf[b0:b0 + n, 3:].sum(0)
+                T = cf[b0:b0 + n, :3].sum(0)                                  # about the agent's subtree CoM, world axes
+                scale = 1.0 + np.abs(F).max()
+                assert np.abs(F - qc[d0:d0 + 3]).max() < 1e-9 * scale, (t, e, ag, F, qc[d0:d0 + 3])
+                T_torso = T + np.cross(com[b0] - xpos[b0], F)                  # shifted to the torso's origin
+                w, x, y, z = xquat[b0]
+                R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                              [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                              [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+                assert np.abs(R.T @ T_torso - qc[d0 + 3:d0 + 6]).max() < 1e-9 * (1.0 + np.abs(T_torso).max()), (t, e, ag)
+                checked += int(np.abs(F).max() > 1.0)
+    assert checked > 100
+    # |clip| in the observation, own bodies and the opponent's torso
+    cf = sim.array("cfrc_ext", 0)          # (of the forward just evaluated: not the step's; the step's is what obs shows)
+    assert np.count_nonzero(out[0][:, :, 29:107]) > 0 and out[0][:, :, 29:107].min() >= 0 and out[0][:, :, 29:107].max() <= 100
