@@ -24,13 +24,16 @@ def main(argv):
     ap.add_argument("--interval", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--stochastic", action="store_true")
+    ap.add_argument("--adjust_z", type=float, default=-0.5, help="Agent._adjust_z of every agent; the reference's evaluator sets -0.5 "
+                    "(eval_robosumo_against_fix.py:108-115): the zoo nets were trained with the tatami surface at z = 0")
+    ap.add_argument("--cfrc_mode", default="zero", choices=["zero", "rne_post"])
     args = ap.parse_args(argv)
     import numpy as np
     from robosumo_selfplay_amd import policy_zoo
     from robosumo_selfplay_amd.model import PPOModel
     from robosumo_selfplay_amd.policies import build_policy
     from robosumo_selfplay_amd.vec_env import make_vec_env
-    env = make_vec_env(args.env, args.num_env, args.seed)
+    env = make_vec_env(args.env, args.num_env, args.seed, adjust_z=args.adjust_z, cfrc_mode=args.cfrc_mode)   # eval_robosumo_against_fix.py:108-115
     policy = build_policy(env, "mlp", value_network="copy", num_hidden=64, activation="relu")
     model = PPOModel(policy=policy, ob_space=env.observation_space[0], ac_space=env.action_space[0], trainable=False,
                      model_scope="model_0")

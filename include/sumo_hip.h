@@ -126,6 +126,14 @@ int sumo_rollout_steps_lstm(sumo_handle_t h, const sumo_rollout_lstm* r, float* 
  *       observation.  Parity: against the oracle's restatement of mj_rnePostConstraint (unpinned: no MuJoCo here).
  * sumo_get_cfrc_ext: HOST float64 [E][nbody][6] of the last step (mode 1). */
 int sumo_set_cfrc_mode(sumo_handle_t h, int mode);
+/* Agent._adjust_z (reference robosumo/robosumo/envs/agents.py:33,155-161): a constant added to the torso height an agent REPORTS --
+ * get_qpos() returns a copy with qpos[2] += _adjust_z, so it shifts the own-z entry (index 2) and the opponent-z entry (index
+ * nq + nv + 6 nbody + 2) of every observation (agents.py:190-214) and both lose tests (sumo.py:147-160: z + adjust_z < 0.29); the
+ * physics state, the xy used by the rewards and sumo_get_state are untouched.  0 (default) = training (run.py:76-77 leaves it
+ * commented out); the reference's evaluation / play scripts set -0.5 on every agent (eval_robosumo_against_fix.py:108-115,
+ * play_fixed.py:23, compare_history_version.py:74): the policy-zoo nets were trained with the tatami surface at z = 0, this fork's
+ * is at z = 0.5.  Applies to sumo_reset / sumo_step / sumo_rollout_steps* alike from the next launch on (synchronises). */
+int sumo_set_adjust_z(sumo_handle_t h, double adjust_z);
 int sumo_get_cfrc_ext(sumo_handle_t h, double* out);
 int sumo_get_state(sumo_handle_t h, double* qpos, double* qvel, double* warm, int32_t* counters /* [E][2] */);
 int sumo_set_state(sumo_handle_t h, const double* qpos, const double* qvel, const double* warm,

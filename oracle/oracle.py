@@ -32,8 +32,9 @@ def lib():
         L.so_destroy.argtypes = [C.c_void_p]
         L.so_last_error.restype = C.c_char_p
         for name in ("so_dims", "so_reset", "so_step", "so_get_state", "so_set_state", "so_forward", "so_mj_step",
-                     "so_get_array", "so_stats", "so_set_maxcon", "so_set_jbcap", "so_set_seeds", "so_set_cfrc_mode"):
+                     "so_get_array", "so_stats", "so_set_maxcon", "so_set_jbcap", "so_set_seeds", "so_set_cfrc_mode", "so_set_adjust_z"):
             getattr(L, name).restype = C.c_int
+        L.so_set_adjust_z.argtypes = [C.c_void_p, C.c_double]
         _LIB = L
     return _LIB
 
@@ -67,6 +68,10 @@ class OracleSim:
         """'zero' (default: what the reference's MuJoCo 2.1 without force sensors yields) or 'rne_post' (cfrc_ext as
         mj_rnePostConstraint fills it at the start of the last mj_step of an env step)."""
         assert self.L.so_set_cfrc_mode(self.h, {"zero": 0, "rne_post": 1}[mode]) == 0
+
+    def set_adjust_z(self, adjust_z):
+        """``Agent._adjust_z`` (agents.py:33,155-161): shifts the observed own / opponent z and the lose test; 0 = training."""
+        assert self.L.so_set_adjust_z(self.h, float(adjust_z)) == 0
 
     def __del__(self):
         try:

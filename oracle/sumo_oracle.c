@@ -62,6 +62,7 @@ struct so_sim {
   sumo_model_t m;
   int N, maxcon, jbcap, maxefc, obs_stride, act_stride;
   int cfrc_mode;      /* 0: cfrc_ext == 0 (the reference's MuJoCo 2.1 without force sensors); 1: as mj_rnePostConstraint fills it */
+  double adjust_z;    /* Agent._adjust_z (agents.py:33): 0 in training (run.py:76-77), -0.5 in the evaluation scripts (eval_robosumo_against_fix.py:108-115) */
   env_t* env;
 };
 
@@ -990,7 +991,8 @@ static void write_obs(const so_sim* s, const env_t* d, float* obs) {
   for (int a = 0; a < 2; a++) {
     float* o = obs + a * s->obs_stride;
     int o_ = 1 - a, k = 0;
-    for (int i = 0; i < anq[a]; i++) o[k++] = (float)d->qpos[aq[a] + i];
+    /* get_qpos(): qpos[2] += self._adjust_z on the returned copy (agents.py:155-161) */
+    for (int i = 0; i < anq[a]; i++) o[k++] = (float)(i == 2 ? d->qpos[aq[a] + i] + s->adjust_z : d->qpos[aq[a] + i]);
     for (int i = 0; i < anv[a]; i++) o[k++] = (float)d->qvel[ad[a] + i];
     /* |clip(cfrc_ext, +-CFRC_CLIP)| of the own bodies and of the opponent's torso (agents.py:13,192-208); zeros in the default mode */
     const int* ab = SUMO_I(m, agent_bodyadr);
@@ -998,7 +1000,7 @@ static void write_obs(const so_sim* s, const env_t* d, float* obs) {
       double v = s->cfrc_mode ? d->cfrc_ext[6 * ab[a] + i] : 0.0;
       o[k++] = (float)fabs(v > 100.0 ? 100.0 : (v < -100.0 ? -100.0 : v));
     }
-    for (int i = 0; i < 7; i++) o[k++] = (float)d->qpos[aq[o_] + i];
+    for (int i = 0; i < 7; i++) o[k++] = (float)(i == 2 ? d->qpos[aq[o_] + i] + s->adjust_z : d->qpos[aq[o_] + i]);   /* opp.get_qpos()[:7] */
     for (int i = 0; i < 6; i++) {
       double v = s->cfrc_mode ? d->cfrc_ext[6 * ab[o_] + i] : 0.0;
       o[k++] = (float)fabs(v > 100.0 ? 100.0 : (v < -100.0 ? -100.0 : v));
@@ -1097,7 +1099,7 @@ static void env_step(const so_sim* s, env_t* d, const float* act, float* obs, do
   for (int a = 0; a < 2; a++) {
     const double* p = d->qpos + aq[a];
     double mx = fabs(p[0]) > fabs(p[1]) ? fabs(p[0]) : fabs(p[1]);
-    lost[a] = (p[2] < 0.29) || (mx >= lim);
+    lost[a] = (p[2] + s->adjust_z < 0.29) || (mx >= lim);   /* sumo.py:147-160: get_qpos()[:3], i.e. the adjusted z */
   }
   double dt = SUMO_F(m, opt)[SUMO_OPT_TIMESTEP] * m->frame_skip;
   int dn = 0;
@@ -1221,6 +1223,10 @@ int so_set_jbcap(so_sim* s, int jbcap) {
 int so_set_cfrc_mode(so_sim* s, int mode) {
   if (mode != 0 && mode != 1) return -1;
   s->cfrc_mode = mode;
+  return 0;
+}
+int so_set_adjust_z(so_sim* s, double adjust_z) {
+  s->adjust_z = adjust_z;
   return 0;
 }
 int so_set_maxcon(so_sim* s, int maxcon) {

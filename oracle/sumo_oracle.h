@@ -41,6 +41,8 @@ int so_stats(const so_sim* s, double* out9); /* forward calls, newton iters, con
 int so_set_maxcon(so_sim* s, int maxcon);
 int so_set_jbcap(so_sim* s, int jbcap); /* capacity of the engine's Jacobian pool in halves (0 = unlimited) */
 int so_set_seeds(so_sim* s, const uint64_t* seeds);
+int so_set_cfrc_mode(so_sim* s, int mode);       /* 0 zero (reference), 1 rne_post */
+int so_set_adjust_z(so_sim* s, double adjust_z); /* Agent._adjust_z, agents.py:33,155-161 (observed z and lose test) */
 
 #ifdef __cplusplus
 }

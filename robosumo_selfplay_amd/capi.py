@@ -60,6 +60,7 @@ def lib():
         L.sumo_get_state.argtypes = [vp] * 5
         L.sumo_set_cfrc_mode.argtypes = [vp, i32]
         L.sumo_get_cfrc_ext.argtypes = [vp, vp]
+        L.sumo_set_adjust_z.argtypes = [vp, C.c_double]
         L.sumo_set_state.argtypes = [vp] * 5
         L.sumo_debug_forward.argtypes = [vp] * 4
         L.sumo_stats.argtypes = [vp, vp]
@@ -68,14 +69,14 @@ def lib():
         L.sumo_debug_trace.restype = i32
         L.sumo_profile.restype = i32
         for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps", "sumo_rollout_steps_lstm", "sumo_get_state",
-                  "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
+                  "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_set_adjust_z", "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
             getattr(L, n).restype = i32
         _LIB = L
     return _LIB
 
 
 EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps",
-           "sumo_rollout_steps_lstm", "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace")
+           "sumo_rollout_steps_lstm", "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_set_adjust_z", "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace")
 
 
 def _np(a):
@@ -134,6 +135,10 @@ class Engine:
     def set_cfrc_mode(self, mode):
         """'zero' (default, the reference's behaviour) or 'rne_post' (include/sumo_hip.h: cfrc_mode)."""
         _chk(lib().sumo_set_cfrc_mode(self.h, {"zero": 0, "rne_post": 1}[mode]))
+
+    def set_adjust_z(self, adjust_z):
+        """``Agent._adjust_z`` of the reference (agents.py:33,155-161; include/sumo_hip.h: sumo_set_adjust_z)."""
+        _chk(lib().sumo_set_adjust_z(self.h, float(adjust_z)))
 
     def get_cfrc_ext(self):
         out = np.zeros((self.N, self.nbody, 6))

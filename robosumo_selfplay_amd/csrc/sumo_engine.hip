@@ -404,6 +404,7 @@ struct Params {  // lives in device memory; read through scalar / per-lane loads
   const LaneRec* lanes;     // [64]
   const int* pair_rec;      // [(wrounds + arounds) * 64] packed pair records (see build_aux)
   const float* pair_bound;  // conservative (rounded-up) reach of each pair
+  double adjust_z;          // Agent._adjust_z (agents.py:33,155-161): added to the z an agent REPORTS -- observations and lose test; 0 in training
 };
 
 template <int NV_>
@@ -1948,15 +1949,17 @@ __device__ __forceinline__ void hand_store(T* p, T v) {
 template <bool COH = false, class C>
 __device__ __forceinline__ void write_obs(C& c, float* obs, int obs_stride, int num_steps) {
   const sumo_model_t& mdl = c.P->mdl;
+  const double adjz = c.P->adjust_z;
   for (int idx = c.lane; idx < 2 * obs_stride; idx += WAVE) {
     int a = idx >= obs_stride, k = idx - a * obs_stride, o = 1 - a;
     int nqa = MI(agent_nq)[a], nva = MI(agent_nv)[a], nba = MI(agent_nbody)[a];
     int dim = nqa + nva + 6 * nba + 14;
     float v = 0.0f;
-    if (k < nqa) v = (float)S(qpos)[MI(agent_qposadr)[a] + k];
+    // get_qpos() adds _adjust_z to the z entry of the copy it returns (agents.py:155-161): own z and the opponent's z
+    if (k < nqa) { double q = S(qpos)[MI(agent_qposadr)[a] + k]; if (k == 2) q += adjz; v = (float)q; }
     else if (k < nqa + nva) v = (float)S(qvel)[MI(agent_dofadr)[a] + (k - nqa)];
     else if (k < nqa + nva + 6 * nba) v = 0.0f;
-    else if (k < nqa + nva + 6 * nba + 7) v = (float)S(qpos)[MI(agent_qposadr)[o] + (k - nqa - nva - 6 * nba)];
+    else if (k < nqa + nva + 6 * nba + 7) { const int j = k - nqa - nva - 6 * nba; double q = S(qpos)[MI(agent_qposadr)[o] + j]; if (j == 2) q += adjz; v = (float)q; }
     else if (k < dim - 1) v = 0.0f;
     else if (k == dim - 1) v = (float)(-1.0 + 2.0 * num_steps / 500.0);
     hand_store<COH>(obs + idx, v);
@@ -2125,10 +2128,11 @@ __device__ __forceinline__ void env_step_body(C& c, const SA& a, int e) {
   }
   num_steps++;
   const double lim = mdl.tatami_size + 0.1;
+  const double adjz = c.P->adjust_z;   // sumo.py:147,157 read get_qpos(): the lose test sees the adjusted z
   int lost[2];
   for (int g = 0; g < 2; g++) {
     double mx = fabs(after[g][0]) > fabs(after[g][1]) ? fabs(after[g][0]) : fabs(after[g][1]);
-    lost[g] = (z[g] < 0.29) || (mx >= lim);
+    lost[g] = (z[g] + adjz < 0.29) || (mx >= lim);
   }
   const double dt = MF(opt)[SUMO_OPT_TIMESTEP] * mdl.frame_skip;
   int dn = 0;
@@ -2707,6 +2711,7 @@ struct sumo_engine {
   signed char* d_pic = nullptr;
   double* d_state = nullptr;
   int cfrc_mode = 0;                       // 0 zero (reference behaviour), 1 rne_post (sumo_set_cfrc_mode)
+  double adjust_z = 0.0;                   // Agent._adjust_z (sumo_set_adjust_z)
   double *d_state_prev = nullptr, *d_fbuf = nullptr, *d_cfrc = nullptr;   // rne_post: pre-step state, row-force scratch, cfrc_ext [N][nbody][6]
   int* d_counters = nullptr;
   uint64_t* d_seeds = nullptr;
@@ -3200,6 +3205,7 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
     Params hp;
     hp.mdl = E->dm; hp.aux = E->aux; hp.L = E->L;
     hp.lanes = E->d_lanes; hp.pair_rec = E->d_pair_rec; hp.pair_bound = E->d_pair_bound;
+    hp.adjust_z = 0.0;
     HIPCHK(hipMalloc((void**)&E->d_params, sizeof(Params)));
     HIPCHK(hipMemcpy(E->d_params, &hp, sizeof(Params), hipMemcpyHostToDevice));
   }
@@ -3491,6 +3497,15 @@ extern "C" int sumo_set_cfrc_mode(sumo_handle_t E, int mode) {
     HIPCHK(hipMemset(E->d_cfrc, 0, (size_t)E->N * 6 * E->hm.nbody * sizeof(double)));
   }
   E->cfrc_mode = mode;
+  return 0;
+}
+extern "C" int sumo_set_adjust_z(sumo_handle_t E, double adjust_z) {
+  if (!E) FAIL(-1, "bad handle");
+  if (!(fabs(adjust_z) <= 1e10)) FAIL(-2, "adjust_z must be finite");
+  HIPCHK(hipSetDevice(E->device));
+  HIPCHK(hipDeviceSynchronize());   // no launch of this engine may be reading the parameter block
+  HIPCHK(hipMemcpy((char*)E->d_params + offsetof(Params, adjust_z), &adjust_z, sizeof(double), hipMemcpyHostToDevice));
+  E->adjust_z = adjust_z;
   return 0;
 }
 extern "C" int sumo_get_cfrc_ext(sumo_handle_t E, double* out) {   // HOST float64 [E][nbody][6] of the last step (rne_post mode)

@@ -296,7 +296,11 @@ class ZooLSTMPolicy(object):
 def load_zoo_policy(path, ac_dim, device=0, kind=None):
     """utils.py:66-67 ``load_params`` + policy construction; ``kind`` 'mlp' / 'lstm' (default: whichever layout fits the
     vector length)."""
-    flat = np.load(path, allow_pickle=False)
+    return load_zoo_policy_from_flat(np.load(path, allow_pickle=False), ac_dim, device=device, kind=kind)
+
+
+def load_zoo_policy_from_flat(flat, ac_dim, device=0, kind=None):
+    """The policy for a flat parameter vector already in memory (utils.py:70-83 ``set_from_flat``)."""
     if kind is None:
         try:
             infer_ob_dim(flat.size, ac_dim)
@@ -324,10 +328,31 @@ class FixedOpponentModel(object):
         raise RuntimeError("the fixed opponent is not replaced by checkpoints")
 
 
-def evaluate_against(model, opponent, env, rounds, deterministic=True):
+EVAL_ADJUST_Z = -0.5   # eval_robosumo_against_fix.py:108-115, play_fixed.py:23, compare_history_version.py:74
+
+
+def evaluate_against(model, opponent, env, rounds, deterministic=True, adjust_z=EVAL_ADJUST_Z):
     """eval_robosumo_against_fix.py:196-230 on the device: ``model`` acts for agent 0 on obs[:, 0], ``opponent`` (zoo
     policy) for agent 1 on obs[:, 1, :ob_dim]; an episode counts as a win if agent 0 carries the 'winner' flag when it
-    ends, a loss if agent 1 does, a draw otherwise.  Returns dict(win, draw, lose, rounds, steps)."""
+    ends, a loss if agent 1 does, a draw otherwise.  Returns dict(win, draw, lose, rounds, steps).
+
+    The reference's evaluator builds its envs with ``agent._adjust_z = -0.5`` on every agent (:108-115): observed heights
+    and the lose test (sumo.py:147-160: ``z + adjust_z < 0.29``) are relative to a tatami surface at z = 0, which is what
+    the zoo nets were trained on.  ``adjust_z`` is imposed on ``env`` for the evaluation and the env's own value restored
+    afterwards (None: leave the env as it is)."""
+    import torch
+    prev_adjust = getattr(env, "adjust_z", 0.0)
+    if adjust_z is not None and float(adjust_z) != prev_adjust:
+        env.set_adjust_z(adjust_z)
+    try:
+        return _evaluate_against(model, opponent, env, rounds, deterministic)
+    finally:
+        if adjust_z is not None and float(adjust_z) != prev_adjust:
+            torch.cuda.synchronize()
+            env.set_adjust_z(prev_adjust)
+
+
+def _evaluate_against(model, opponent, env, rounds, deterministic):
     import torch
     obs = env.reset_device()
     A0, A1 = env.model.act_dims

@@ -64,7 +64,7 @@ class EnvSpec(object):
 
 class SumoVecEnv(VecEnv):
     def __init__(self, env_id="RoboSumo-Ant-vs-Ant-v0", num_envs=1, seed=0, device=0, asset_dir=None, model=None, groups=1,
-                 cfrc_mode="zero"):
+                 cfrc_mode="zero", adjust_z=0.0):
         """``groups`` > 1 splits the envs into that many equal, contiguous groups, each with its own engine: a group's step is
         its own kernel launch (``step_device_group``), so a caller that advances the groups on separate streams is not held
         back by the slowest env of the whole batch at every step (the device-mode Runner does that).  All buffers stay
@@ -88,6 +88,12 @@ class SumoVecEnv(VecEnv):
         if cfrc_mode != "zero":
             for E_ in self.engines:
                 E_.set_cfrc_mode(cfrc_mode)
+        # Agent._adjust_z (agents.py:33,155-161): offset of the z an agent REPORTS (observations, lose test).  0 = training
+        # (run.py:76-77); the reference's evaluation / play scripts set -0.5 (eval_robosumo_against_fix.py:108-115)
+        self.adjust_z = float(adjust_z)
+        if self.adjust_z != 0.0:
+            for E_ in self.engines:
+                E_.set_adjust_z(self.adjust_z)
         self.engine = self.engines[0]                                   # dimensions / limits (identical for every group)
         E = self.engine
         obs_dims, act_dims = self.model.obs_dims, self.model.act_dims
@@ -165,6 +171,13 @@ class SumoVecEnv(VecEnv):
         for g in range(self.groups):
             self.step_device_group(g, actions)
         return self.obs_dev, self.info_dev, self.done_dev, self.ep_r_dev, self.ep_dr_dev, self.ep_l_dev
+
+    def set_adjust_z(self, adjust_z):
+        """Counterpart of ``for agent in env.agents: agent._adjust_z = v`` (eval_robosumo_against_fix.py:110-112)."""
+        self._assert_not_closed()
+        self.adjust_z = float(adjust_z)
+        for E_ in self.engines:
+            E_.set_adjust_z(self.adjust_z)
 
     def stats(self):
         """Solver / contact statistics summed over the groups' engines (maxima for the ``max_*`` entries)."""

@@ -41,6 +41,9 @@ def main(argv):
                     "launch that balances the envs itself (MLP policies, LSTM policies with nlstm 128), 2 for step-by-step launches on two streams")
     ap.add_argument("--cfrc_mode", default="zero", choices=["zero", "rne_post"], help="contact-force observation entries: zero = the reference's "
                     "behaviour (MuJoCo 2.1 without force sensors), rne_post = as mj_rnePostConstraint would fill them (second launch per step)")
+    ap.add_argument("--adjust_z", type=float, default=0.0, help="Agent._adjust_z (agents.py:33): offset of the torso height the agents report "
+                    "(observations, lose test).  0 = the reference's training setting (its run.py:76-77 leaves the -0.5 commented out); its "
+                    "evaluation / play scripts use -0.5, which is what the policy-zoo nets expect")
     args, unknown = ap.parse_known_args(argv)
     extra = parse_unknown(unknown)
     from robosumo_selfplay_amd import alg_ppo, defaults, dist as sdist
@@ -59,7 +62,7 @@ def main(argv):
     groups = args.env_groups if per % max(1, args.env_groups) == 0 else 1
     import torch
     local_rank = local_rank % max(1, torch.cuda.device_count())        # gloo rehearsal of N ranks on fewer GPUs
-    env = make_vec_env(args.env, per, args.seed + start, device=local_rank, groups=groups, cfrc_mode=args.cfrc_mode)  # run.py:144: env i gets seed + i
+    env = make_vec_env(args.env, per, args.seed + start, device=local_rank, groups=groups, cfrc_mode=args.cfrc_mode, adjust_z=args.adjust_z)  # run.py:144: env i gets seed + i
     kw = defaults.get_default_params(args.env, args.algo)
     kw.update(extra)
     if args.network == "lstm":       # the RoboSumo defaults describe the MLP (defaults.py:8-26); recurrent nets share the latent
