@@ -145,6 +145,7 @@ def spider_segment(torch, dev, local_rank, args, hp):
     e1.record()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    check_rollout(env, fused)
     st1 = env.stats()
     nf = max(1.0, st1["forward"] - st0["forward"])
     out = {"env_id": env_id, "envs": N, "steps": args.spider_steps, "env_steps_per_s": N * args.spider_steps / dt,
@@ -192,11 +193,20 @@ def recurrent_segment(torch, dev, local_rank, args, hp):
     r.join_groups()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    check_rollout(env, fused)
     out = {"env_id": env_id, "envs": N, "steps": K, "policy": "lstm(128), shared value head", "opponent_pool": P,
            "env_steps_per_s": N * K / dt, "ms_per_step": dt / K * 1e3, "rollout_path": "fused" if fused else "stepwise",
            "note": "1024 envs leave half of the chip's 2048 wave slots empty: the launch lasts as long as its slowest env's chain of steps"}
     env.close()
     return out
+
+
+def check_rollout(env, fused):
+    """A fused launch that was cut short would make the timed number meaningless (and leave garbage rows): raise, outside the
+    timed region (capi.Engine.rollout_status -> sumo_rollout_status)."""
+    if fused:
+        for E in env.engines:
+            E.rollout_status()
 
 
 def cpu_baseline(model, states, actions, steps, threads):
@@ -354,6 +364,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     thr1 = hostcfg.throttle_stats()
+    check_rollout(env, fused)
     if fused:
         timed = [0]
     kern_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in timed])) if timed else float("nan")   # fused: the K-step launch

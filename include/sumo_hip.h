@@ -141,10 +141,20 @@ int sumo_set_state(sumo_handle_t h, const double* qpos, const double* qvel, cons
 /* debug / parity hook: run mj_forward once per env at its current state with ctrl (HOST float64 [E][nu]) and return
  * qacc (HOST float64 [E][nv]) plus per-env {ncon, nefc, newton iterations, dropped contacts} (HOST int32 [E][4]). */
 int sumo_debug_forward(sumo_handle_t h, const double* ctrl, double* qacc, int32_t* counts);
+/* Outcome of the engine's most recent sumo_rollout_steps* launch; waits for that launch (its stream) to finish.
+ * A MuJoCo fault is loud in the reference (mujoco-py/mujoco_py/builder.py:351-369 raises MujocoException out of env.step); so is a
+ * fused launch that did not complete: returns -20 (sumo_last_error() says why) when the launch's abort flag is set -- a wave's bounded
+ * wait for its env's previous step expired, or the record a wave took over did not carry the sequence tag / checksum its writer
+ * published (every hand-over is checked) -- and 0 otherwise.  After -20 the rollout buffers hold unwritten rows and the env states
+ * are partly advanced: reset before continuing.  out4 (HOST, may be NULL): {abort flag, tickets drawn, tickets of the launch
+ * (E x K), hand-over mismatches since creation}.  Runner.run (device mode) and bench.py call this after every rollout. */
+int sumo_rollout_status(sumo_handle_t h, int64_t* out4);
+/* development / tests: the first hand-over of env `env` in the following fused launches carries a wrong checksum (-1 = off) */
+int sumo_debug_fault(sumo_handle_t h, int env);
 /* device-side statistics accumulated since creation: forward calls, newton iterations, contacts, efc rows,
  * max ncon, max nefc, max newton iterations, dropped contacts, diverged env steps, aborted waits of the fused rollout's step
- * hand-over (always 0 unless a launch was cut short) (HOST float64 [SUMO_NSTATS]). */
-#define SUMO_NSTATS 10
+ * hand-over, hand-over tag / checksum mismatches (both always 0 unless a launch was cut short) (HOST float64 [SUMO_NSTATS]). */
+#define SUMO_NSTATS 11
 int sumo_stats(sumo_handle_t h, double* out);
 /* per-phase shader-cycle totals (20 phases + 4 ad-hoc probe slots); all zero unless the library was built with
  * -DSUMO_PROFILE (HOST float64 [24]). */

@@ -158,7 +158,9 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
     tfirststart = time.perf_counter()
     history = dict(version_gap=[], off_policy_ratio_mean=[], off_env_ratio_mean=[], total_ratio_mean=[], off_policy_ratio_clip_frac=[],
                    off_env_ratio_clip_frac=[], total_ratio_clip_frac=[], useful_ratio=[], opponent_versions=[], ppo_clip_frac=[],
-                   approxkl=[], early_stop_info=[], lossvals=[], fps=[], rollout_s=[], update_s=[])
+                   approxkl=[], early_stop_info=[], lossvals=[], fps=[], rollout_s=[], update_s=[],
+                   env_diverged=[], env_dropped_contacts=[], env_rollout_aborts=[])     # per update, from the engine's counters
+    env_stats_prev = env.stats() if hasattr(env, "stats") else None
     nupdates = total_timesteps // nbatch
     idx_choice = 0
     opponent_obs = opponent_actions = None
@@ -298,14 +300,29 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         history["rollout_s"].append(t_roll)
         history["update_s"].append(tnow - tstart - t_roll)
         history["fps"].append(nbatch * world / (tnow - tstart))
+        # the engine's fault counters of this update (the reference is loud here: a MuJoCo warning raises MujocoException,
+        # mujoco-py builder.py:351-369; the fused launch's abort already raised in Runner.run): diverged env steps (episodes ended
+        # by the bad-value guard), contacts dropped for lack of room, aborted hand-over waits
+        env_note = ""
+        if env_stats_prev is not None:
+            st_now = env.stats()
+            dv, dc = st_now["diverged"] - env_stats_prev["diverged"], st_now["dropped"] - env_stats_prev["dropped"]
+            ab = (st_now["rollout_aborts"] + st_now.get("handover_mismatches", 0)
+                  - env_stats_prev["rollout_aborts"] - env_stats_prev.get("handover_mismatches", 0))
+            env_stats_prev = st_now
+            history["env_diverged"].append(int(dv)); history["env_dropped_contacts"].append(int(dc)); history["env_rollout_aborts"].append(int(ab))
+            if dv or dc or ab:
+                env_note = "  [env: %d diverged steps, %d dropped contacts, %d rollout aborts]" % (dv, dc, ab)
         if update_fn is not None:
             update_fn(update)
         if verbose and rank == 0 and (update % log_interval == 0 or update == 1):
             ev = explained_variance(b_val.cpu().numpy(), b_ret.cpu().numpy())
             print("update %d/%d  fps %.0f  rollout %.2fs  sgd %.2fs  ev %.3f  eprewmean %.2f  eplenmean %.1f  %s" % (
                 update, nupdates, history["fps"][-1], t_roll, tnow - tstart - t_roll, ev, safemean([e["r"] for e in epinfobuf]),
-                safemean([e["l"] for e in epinfobuf]), " ".join("%s %.4g" % (n, v) for n, v in zip(model.loss_names, lossvals))),
+                safemean([e["l"] for e in epinfobuf]), " ".join("%s %.4g" % (n, v) for n, v in zip(model.loss_names, lossvals))) + env_note,
                 flush=True)
+        elif env_note and rank == 0:
+            print("update %d/%d%s" % (update, nupdates, env_note), flush=True)
         if save_interval and (update % save_interval == 0 or update == 1) and rank == 0:
             model.save(osp.join(checkdir, "%.5i" % update))               # alg_ppo.py:459-464
         if comm is not None:

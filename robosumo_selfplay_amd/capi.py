@@ -12,7 +12,7 @@ from . import build as _build
 
 INFO_STRIDE = 8
 NDIMS = 16
-NSTATS = 10
+NSTATS = 11
 _LIB = None
 
 
@@ -67,6 +67,10 @@ def lib():
         L.sumo_profile.argtypes = [vp, vp]
         L.sumo_debug_trace.argtypes = [vp, vp]
         L.sumo_debug_trace.restype = i32
+        L.sumo_rollout_status.argtypes = [vp, vp]
+        L.sumo_rollout_status.restype = i32
+        L.sumo_debug_fault.argtypes = [vp, i32]
+        L.sumo_debug_fault.restype = i32
         L.sumo_profile.restype = i32
         for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps", "sumo_rollout_steps_lstm", "sumo_get_state",
                   "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_set_adjust_z", "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
@@ -76,7 +80,8 @@ def lib():
 
 
 EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps",
-           "sumo_rollout_steps_lstm", "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_set_adjust_z", "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace")
+           "sumo_rollout_steps_lstm", "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_set_adjust_z", "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace",
+           "sumo_rollout_status", "sumo_debug_fault")
 
 
 def _np(a):
@@ -189,4 +194,15 @@ class Engine:
         o = np.zeros(NSTATS)
         _chk(lib().sumo_stats(self.h, _np(o)))
         return dict(forward=o[0], newton=o[1], contacts=o[2], efc=o[3], max_ncon=o[4], max_nefc=o[5],
-                    max_newton=o[6], dropped=o[7], diverged=o[8], rollout_aborts=o[9])
+                    max_newton=o[6], dropped=o[7], diverged=o[8], rollout_aborts=o[9], handover_mismatches=o[10])
+
+    def rollout_status(self):
+        """Waits for the engine's most recent fused rollout launch and RAISES if it was cut short (``sumo_rollout_status``:
+        expired hand-over wait or a hand-over tag / checksum mismatch).  Returns dict(aborted, tickets_drawn, tickets, mismatches)."""
+        o = np.zeros(4, np.int64)
+        _chk(lib().sumo_rollout_status(self.h, _np(o)))
+        return dict(aborted=int(o[0]), tickets_drawn=int(o[1]), tickets=int(o[2]), mismatches=int(o[3]))
+
+    def debug_fault(self, env):
+        """Tests: make the first hand-over of ``env`` in the following fused launches carry a wrong checksum (-1 = off)."""
+        _chk(lib().sumo_debug_fault(self.h, int(env)))

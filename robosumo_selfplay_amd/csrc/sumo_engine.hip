@@ -122,6 +122,11 @@ struct StepArgs {
   unsigned long long* stats;
   int obs_stride, act_stride;
   int N;
+  // fused rollout (sumo_rollout_kernel): hand-over tag of this launch (tag of an env after its k-th step = seq_base + k), the
+  // launch's abort flag, development fault injection (env whose first hand-over carries a wrong checksum; -1 = off)
+  int seq_base;
+  int* abort_flag;
+  int dbg_fault_env;
   // debug forward
   const double* dbg_ctrl;
   double* dbg_qacc;
@@ -2023,21 +2028,47 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.tprev = clock64();
 #endif
 }
+// Checksum of a state record as it crosses between waves in the fused rollout launch (COH): every word is mixed with its index,
+// the lanes' contributions are summed over the wave.  The writer stores it next to the record's sequence tag (counters[2..3]),
+// the wave that takes the env over recomputes it from what it LOADED: a stale or torn read of the record -- the failure the
+// hand-rolled sc1 protocol would produce silently -- raises the launch's abort flag instead (sumo_rollout_status).
+__device__ __forceinline__ unsigned rec_hash(double v, int i) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  return (lo ^ (hi * 0x9E3779B1u)) * 0x85EBCA77u + (unsigned)(i + 1) * 0xC2B2AE3Du;
+}
+__device__ __forceinline__ unsigned wave_usum(unsigned v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
 template <bool COH = false, class C, class SA>   // SA: StepArgs by value (per-step kernel) or in the kernel-argument segment (rollout kernel)
-__device__ __forceinline__ void load_state(C& c, const SA& a, int e) {
+__device__ __forceinline__ unsigned load_state(C& c, const SA& a, int e) {   // returns the record's checksum (COH) or 0
   const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
   const double* st = a.state + (size_t)e * a.state_stride;
+  unsigned h = 0;
   for (int i = lane; i < nq + 2 * nv; i += WAVE) {
     double v = hand_load<COH>(st + i);
+    if (COH) h += rec_hash(v, i);
     if (i < nq) S(qpos)[i] = v; else if (i < nq + nv) S(qvel)[i - nq] = v; else S(warm)[i - nq - nv] = v;
   }
+  return COH ? wave_usum(h) : 0u;
 }
 template <bool COH = false, class C, class SA>
-__device__ __forceinline__ void store_state(C& c, const SA& a, int e) {
+__device__ __forceinline__ unsigned store_state(C& c, const SA& a, int e) {
   const int nq = c.P->mdl.nq, nv = c.P->mdl.nv, lane = c.lane;
   double* st = a.state + (size_t)e * a.state_stride;
-  for (int i = lane; i < nq + 2 * nv; i += WAVE)
-    hand_store<COH>(st + i, i < nq ? S(qpos)[i] : (i < nq + nv ? S(qvel)[i - nq] : S(warm)[i - nq - nv]));
+  unsigned h = 0;
+  for (int i = lane; i < nq + 2 * nv; i += WAVE) {
+    const double v = i < nq ? S(qpos)[i] : (i < nq + nv ? S(qvel)[i - nq] : S(warm)[i - nq - nv]);
+    if (COH) h += rec_hash(v, i);
+    hand_store<COH>(st + i, v);
+  }
+  return COH ? wave_usum(h) : 0u;
 }
 template <class C>
 __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
@@ -2096,7 +2127,19 @@ __device__ __forceinline__ void env_step_body(C& c, const SA& a, int e) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane;
   if (a.trace && lane == 0) a.trace[4 * e] = wall_clock64();
-  load_state<COH>(c, a, e);
+  const unsigned rec_sum = load_state<COH>(c, a, e);
+  if (COH) {   // fused rollout: the record must be the one the env's previous step of THIS launch published (tag and checksum)
+    const int k0 = ((const int*)(S(stash) + 4))[1];   // parked by the ticket loop
+    if (k0 > 0) {
+      const int* cn = a.counters + 4 * e;
+      const int tag = hand_load<true>(cn + 2);
+      const unsigned chk = (unsigned)hand_load<true>(cn + 3);
+      if ((tag != a.seq_base + k0 || chk != rec_sum) && lane == 0) {
+        __hip_atomic_store(pt_global(a.abort_flag), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.stats) atomicAdd(a.stats + 10, 1ull);
+      }
+    }
+  }
   if (!COH && lane < mdl.nu) {   // fused rollout: the policy phase has put the step's actions into S(ctrl) itself
     const float PT_GAS* act0 = pt_global(a.actions) + (size_t)e * 2 * a.act_stride;
     int ag = lane >= MI(agent_uadr)[1] ? 1 : 0;
@@ -2194,7 +2237,12 @@ __device__ __forceinline__ void env_step_body(C& c, const SA& a, int e) {
     num_steps = 0; ep_ret = 0; ep_dense = 0;
   }
   write_obs<COH>(c, a.obs + (size_t)e * 2 * a.obs_stride, a.obs_stride, num_steps);
-  store_state<COH>(c, a, e);
+  const unsigned rec_out = store_state<COH>(c, a, e);
+  if (COH && lane == 0) {   // sequence tag + checksum of the record just written (the next wave checks them first)
+    const int k1 = ((const int*)(S(stash) + 4))[1] + 1;
+    hand_store<true>(cnt + 3, (int)(rec_out + (unsigned)(k1 == 1 && a.dbg_fault_env == e)));   // dbg_fault_env: injected fault (tests)
+    hand_store<true>(cnt + 2, a.seq_base + k1);
+  }
   if (lane == 0) {
     hand_store<COH>(cnt, num_steps); hand_store<COH>(cnt + 1, reset_count);
     hand_store<COH>(st + mdl.nq + 2 * mdl.nv, ep_ret); hand_store<COH>(st + mdl.nq + 2 * mdl.nv + 1, ep_dense);
@@ -2589,7 +2637,10 @@ sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
     int* sched = lp->r.sched;                      // [0] ticket counter, [1] abort flag, [2 + e] finished steps of env e
     const int N = lp->a.N;
     int t = 0;
-    if (c.lane == 0) t = __hip_atomic_fetch_add(sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c.lane == 0) {
+      t = __hip_atomic_fetch_add(sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_load(sched + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) t = 0x7FFFFFFF;   // launch aborted: drain
+    }
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= N * lp->r.K) break;
     int e = t % N, k = t / N;
@@ -2721,6 +2772,11 @@ struct sumo_engine {
   unsigned long long* d_trace = nullptr;   // sumo_debug_trace
   int num_cus = 0;                         // cached device property (sumo_rollout_steps sizes its persistent grid with it)
   int* d_rsched = nullptr;                 // sumo_rollout_steps: ticket counter, abort flag, per-env progress [2 + N]
+  unsigned rollout_seq = 0;                // fused launches so far (hand-over tags: seq_base = (rollout_seq & 0x7FFF) << 16)
+  hipStream_t rollout_stream = nullptr;    // stream of the most recent fused launch (sumo_rollout_status waits on it)
+  long long rollout_tickets = -1;          // N * K of the most recent fused launch, -1: none yet
+  int dbg_fault_env = -1;                  // sumo_debug_fault
+  unsigned long long acked_faults = 0;     // stats[9] + stats[10] already reported by sumo_rollout_status
   long long sched_t = 0;                                                                     // step launches so far (in-kernel ranking)
   void* d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
@@ -3298,6 +3354,7 @@ static StepArgs base_args(sumo_engine* E) {
   memset(&a, 0, sizeof a);
   a.state = E->d_state; a.counters = E->d_counters; a.seeds = E->d_seeds; a.state_stride = E->state_stride;
   a.stats = E->d_stats; a.obs_stride = E->obs_stride; a.act_stride = E->act_stride; a.N = E->N;
+  a.dbg_fault_env = -1;
   return a;
 }
 
@@ -3383,6 +3440,13 @@ static int rollout_launch(sumo_engine* E, const RolloutArgs& r, int policy, floa
   if (!E->d_rsched) HIPCHK(hipMalloc((void**)&E->d_rsched, (size_t)(2 + E->N) * sizeof(int)));
   HIPCHK(hipMemsetAsync(E->d_rsched, 0, (size_t)(2 + E->N) * sizeof(int), st_));
   rl.r.sched = E->d_rsched;
+  if (r.K >= 65536) FAIL(-5, "K = %d: at most 65535 steps per fused launch", r.K);
+  E->rollout_seq++;
+  a.seq_base = (int)((E->rollout_seq & 0x7FFFu) << 16);
+  a.abort_flag = E->d_rsched + 1;
+  a.dbg_fault_env = E->dbg_fault_env;
+  E->rollout_stream = st_;
+  E->rollout_tickets = (long long)E->N * r.K;
   // persistent waves: as many as the chip holds at this kernel's LDS footprint (8 per CU at most: two per SIMD)
   int slots = (int)((size_t)160 * 1024 / (size_t)E->L.total_bytes);
   if (slots > 4 * SUMO_WPE_OF(E->hm.nv)) slots = 4 * SUMO_WPE_OF(E->hm.nv);
@@ -3514,6 +3578,33 @@ extern "C" int sumo_get_cfrc_ext(sumo_handle_t E, double* out) {   // HOST float
   HIPCHK(hipSetDevice(E->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, E->d_cfrc, (size_t)E->N * 6 * E->hm.nbody * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int sumo_rollout_status(sumo_handle_t E, int64_t* out4) {
+  if (!E) FAIL(-1, "bad handle");
+  long long o[4] = {0, 0, E->rollout_tickets < 0 ? 0 : E->rollout_tickets, 0};
+  if (E->rollout_tickets >= 0) {
+    HIPCHK(hipSetDevice(E->device));
+    HIPCHK(hipStreamSynchronize(E->rollout_stream));
+    int sc[2];
+    unsigned long long st[2];
+    HIPCHK(hipMemcpy(sc, E->d_rsched, sizeof sc, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st, E->d_stats + 9, sizeof st, hipMemcpyDeviceToHost));
+    // the counters accumulate over launches: an earlier chunk's abort (whose flag the next launch's memset has cleared) still shows
+    const bool cut = sc[1] != 0 || st[0] + st[1] != E->acked_faults;
+    E->acked_faults = st[0] + st[1];
+    o[0] = cut; o[1] = sc[0]; o[3] = (long long)st[1];
+    if (out4) for (int i = 0; i < 4; i++) out4[i] = o[i];
+    if (cut)
+      FAIL(-20, "fused rollout launch was cut short (abort flag set: %llu expired hand-over waits, %llu hand-over tag / checksum mismatches "
+                "since creation; %d of %lld tickets were drawn): the rollout buffers hold unwritten rows and the env states are "
+                "partly advanced -- reset the envs before continuing", st[0], st[1], sc[0], E->rollout_tickets);
+  } else if (out4) for (int i = 0; i < 4; i++) out4[i] = o[i];
+  return 0;
+}
+extern "C" int sumo_debug_fault(sumo_handle_t E, int env) {
+  if (!E) FAIL(-1, "bad handle");
+  E->dbg_fault_env = env;
   return 0;
 }
 extern "C" int sumo_debug_trace(sumo_handle_t E, uint64_t* stamps_dev) {

@@ -94,20 +94,42 @@ def apply(threads=None):
     return threads
 
 
+_captures_open = 0      # HIP graph captures in progress in this process (gc_paused blocks)
+
+
+def capturing():
+    return _captures_open > 0
+
+
+def drop_graphs(graphs):
+    """The ONE place captured HIP graphs are released (``graphs``: a dict of capture records).  Destroying a graph while a stream of
+    the process is capturing aborts the process; the cyclic collector is held off by ``gc_paused``, and this guard covers the other
+    route -- a reference count reaching zero inside a capture block."""
+    if _captures_open:
+        raise RuntimeError("a captured HIP graph would be destroyed while a graph capture is open (hostcfg.gc_paused): "
+                           "release graphs before entering the capture block")
+    graphs.clear()
+
+
 class gc_paused(object):
     """Context manager for HIP graph capture: collect garbage now, then keep the cyclic collector off until the block ends.  A
     collection that happens to run inside a capture may finalise device objects of an earlier model (its captured graphs, streams,
-    events); destroying those while a stream is capturing aborts the process."""
+    events); destroying those while a stream is capturing aborts the process.  While the block is open ``capturing()`` is true and
+    ``drop_graphs`` refuses to release graphs."""
 
     def __enter__(self):
         import gc
+        global _captures_open
         self._was = gc.isenabled()
         gc.collect()
         gc.disable()
+        _captures_open += 1
         return self
 
     def __exit__(self, *exc):
         import gc
+        global _captures_open
+        _captures_open -= 1
         if self._was:
             gc.enable()
         return False

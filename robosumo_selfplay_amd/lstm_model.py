@@ -254,7 +254,7 @@ class LstmPPOModel(object):
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= 2:
-                self._graphs.clear()
+                hostcfg.drop_graphs(self._graphs)
             try:
                 static = [t.empty(x.shape, dtype=x.dtype, device=self.device) for x in tensors]
                 for d, x in zip(static, tensors):
@@ -276,7 +276,7 @@ class LstmPPOModel(object):
                 ent = self._graphs[key] = dict(graph=graph, static=static)
             except Exception as e:                 # capture unsupported here: eager launches from now on
                 type(self).use_graph = False
-                self._graphs.clear()
+                hostcfg.drop_graphs(self._graphs)
                 import warnings
                 warnings.warn("HIP graph capture of the recurrent PPO step failed (%r); using eager launches" % (e,))
                 return False

@@ -124,7 +124,7 @@ class PPOModel(object):
         shp = (tuple(obs.shape), obs.stride(0), tuple(weights.shape))
         if self._static is None or self._static["shape"] != shp:
             self._static = dict(shape=shp, bufs=[t.empty_like(x, memory_format=t.contiguous_format) for x in arrs])
-            self._graphs.clear()
+            hostcfg.drop_graphs(self._graphs)
         for dst, x in zip(self._static["bufs"], arrs):
             dst.copy_(x)
         self._static["open"] = True
@@ -141,7 +141,7 @@ class PPOModel(object):
         g = self._graphs.get(key)
         if g is None:
             if len(self._graphs) >= 2:
-                self._graphs.clear()
+                hostcfg.drop_graphs(self._graphs)
             try:
                 ent = dict(idx=t.zeros(n, dtype=t.int32, device=self.device), adv=t.empty(n, dtype=t.float32, device=self.device),
                            log_ratio=t.empty(n, dtype=t.float32, device=self.device), keep=(obs, returns, actions, values, neglogpacs, weights))
@@ -163,7 +163,7 @@ class PPOModel(object):
                 g = self._graphs[key] = ent
             except Exception as e:                     # capture unsupported here: stay on the eager path for good
                 type(self).use_graph = False
-                self._graphs.clear()
+                hostcfg.drop_graphs(self._graphs)
                 import warnings
                 warnings.warn("HIP graph capture of the PPO step failed (%r); using eager launches" % (e,))
                 return None

@@ -459,6 +459,12 @@ class Runner(AbstractEnvRunner):
             learner.evaluate(self.obs[:, 0, :], ppo_capi.FWD_VF, out=dict(value=last_values[0]))   # runner.py:184: always models[0]
             learner.evaluate(self.obs[:, 1, :], ppo_capi.FWD_VF, out=dict(value=last_values[1]))
         returns, opr, oer, ratio = self._vtrace(B["rew"], B["val"], B["nlp"], B["onlp"], B["done"], self.dones.contiguous(), last_values)
+        # A fused launch that was cut short (expired hand-over wait, hand-over tag / checksum mismatch) leaves unwritten rollout rows:
+        # fail as loudly as a MuJoCo fault does in the reference (mujoco-py builder.py:351-369 raises out of env.step) instead of
+        # training on them.  The call waits for the launch; this function synchronises right below anyway.
+        if self.fused_ok() or self.fused_lstm_ok():
+            for E in self.env.engines:
+                E.rollout_status()
         # episode infos of agent 0 (monitor.py:63-78), harvested with one host sync per rollout
         d = B["ep_done"].cpu().numpy().astype(bool)
         rr, ll = B["ep_r"].cpu().numpy(), B["ep_l"].cpu().numpy()

@@ -52,9 +52,13 @@ def test_adjust_z_step_parity(env_id, tol):
     ndone = 0
     for t in range(30):
         a = (rng.standard_normal((p.N, 2, p.eng.act_stride)) * 2.0).astype(np.float32)
-        if t == 10:     # lay agent 0 of a few envs on the mat: z - 0.5 < 0.29 -> lost (would not be with adjust_z = 0)
+        lay = t == 10 and env_id == "RoboSumo-Ant-vs-Ant-v0"
+        if lay:         # lay agent 0 of a few envs on the mat, legs folded up: z - 0.5 < 0.29 -> lost (would not be with adjust_z = 0)
             q, v, w, c = p.ora.get_state()
-            q[:8, 2] = 0.77
+            q[:8, 2] = 0.76
+            q[:8, 7:15] = [0.0, 1.0, 0.0, -1.0, 0.0, -1.0, 0.0, 1.0]
+            v[:8] = 0.0
+            a[:8] = 0.0
             p.ora.set_state(q, v, w, c); p.eng.set_state(q, v, w, c)
         (gobs, ginfo, gdone, gr, gdr, gl), (oobs, oinfo, odone, orr, odr, ol) = p.step(a)
         assert np.array_equal(gdone, odone) and np.array_equal(gl, ol)
@@ -63,11 +67,11 @@ def test_adjust_z_step_parity(env_id, tol):
         else:
             assert np.abs(gobs - oobs).max() < 1e-5
         assert relerr(ginfo, oinfo) < tol
-        if t == 10:
+        if lay:
             assert gdone[:8, 0].all() and (ginfo[:8, 0, 1] == -2000).all()
         ndone += int(gdone[:, 0].sum())
         p.eng.set_state(*p.ora.get_state())
-    assert ndone >= 8
+    assert ndone >= (8 if env_id == "RoboSumo-Ant-vs-Ant-v0" else 0)
     # the state itself is not shifted
     assert abs(p.eng.get_state()[0][:, 2].mean() - (p.obs[:, 0, 2].double().mean().item() + 0.5)) < 1e-6
 

@@ -86,3 +86,19 @@ def test_gc_paused_restores_collector_state():
         assert not gc.isenabled()                 # was off before: stays off
     finally:
         gc.enable()
+
+
+def test_drop_graphs_refuses_inside_a_capture_block():
+    """A captured HIP graph destroyed while a stream is capturing aborts the process: the release path raises instead."""
+    import pytest
+    from robosumo_selfplay_amd import hostcfg
+    graphs = {"k": object()}
+    assert not hostcfg.capturing()
+    with hostcfg.gc_paused():
+        assert hostcfg.capturing()
+        with pytest.raises(RuntimeError, match="graph capture is open"):
+            hostcfg.drop_graphs(graphs)
+        assert graphs                              # nothing was released
+    assert not hostcfg.capturing()
+    hostcfg.drop_graphs(graphs)
+    assert not graphs
