@@ -41,7 +41,7 @@ F64_VALU_PEAK_TF = 78.6   # MI355X vector f64 peak (256 CUs x 4 SIMDs x 16 lanes
 F32_MFMA_PEAK_TF = 157.3  # dense f32 matrix-core peak (v_mfma_f32_*_f32), same guide
 
 
-def mfma_probe(torch, dev, learner, opponent, env, obs_b, ret_b, act_b, val_b, nlp_b, nmb_rows, reps=20):
+def mfma_probe(torch, dev, learner, opponent, env, obs_b, ret_b, act_b, val_b, nlp_b, nmb_rows, reps=20, use_graph=True):
     """MFMA side of the roofline, measured live with HIP events on the launching stream: `reps` back-to-back calls of ppo_grad on one
     PPO2 minibatch (forward + backward + weight-gradient MFMAs of both nets; the call also runs the two slab-reduction kernels,
     which are counted in the time but not in the flops) and of ppo_selfplay_forward on one env group (the 5 evaluations of a
@@ -83,18 +83,25 @@ def mfma_probe(torch, dev, learner, opponent, env, obs_b, ret_b, act_b, val_b, n
             call()
         torch.cuda.synchronize(dev)
         # the calls are replayed from a HIP graph so that the GPU, not the Python enqueue loop, sets the pace
-        eager = S["st"]
-        graph = torch.cuda.CUDAGraph()
-        with hostcfg.gc_paused(), torch.cuda.graph(graph):
-            S["st"] = torch.cuda.current_stream(dev).cuda_stream
-            for _ in range(reps):
-                call()
-        S["st"] = eager
-        graph.replay()
+        # (use_graph=False: plain launches, for counter collection under rocprofv3 -- tools/prof_workload.py)
+        if use_graph:
+            eager = S["st"]
+            graph = torch.cuda.CUDAGraph()
+            with hostcfg.gc_paused(), torch.cuda.graph(graph):
+                S["st"] = torch.cuda.current_stream(dev).cuda_stream
+                for _ in range(reps):
+                    call()
+            S["st"] = eager
+            replay = graph.replay
+        else:
+            def replay():
+                for _ in range(reps):
+                    call()
+        replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
         e0.record()
-        graph.replay()
+        replay()
         e1.record()
         torch.cuda.synchronize(dev)
         us = e0.elapsed_time(e1) * 1e3 / reps

@@ -133,7 +133,7 @@ class OracleSim:
         return out[:n].copy()
 
     def stats(self):
-        o = np.zeros(9)
+        o = np.zeros(11)
         self.L.so_stats(self.h, _p(o))
         return dict(forward=o[0], newton=o[1], contacts=o[2], efc=o[3], max_ncon=o[4], max_nefc=o[5],
-                    max_newton=o[6], dropped=o[7], diverged=o[8])
+                    max_newton=o[6], dropped=o[7], diverged=o[8], capsule_box_3=o[9], rod_endcap=o[10])

@@ -54,6 +54,7 @@ typedef struct {
   double *Ma, *grad, *Mgrad, *search, *Mv, *Jv, *H, *tmpv;
   double *rkX[4], *rkF[4], *rkdX;
   long n_forward, n_newton, n_contacts, n_efc, max_ncon, max_nefc, max_newton, n_diverged;
+  long n_cb3, n_rodcap; /* fidelity accounting: capsule-box calls with 3 active contacts; active contacts on a border rod beyond the cylinder's flat end */
   double* cfrc_ext;   /* [nbody][6] (cfrc_mode = rne_post): contact wrenches about the root's subtree CoM, world axes, [torque ; force] */
 } env_t;
 
@@ -511,6 +512,18 @@ static void collision(const so_sim* s, env_t* d) {
       else if (u1 == SUMO_GEOM_SPHERE && u2 == SUMO_GEOM_BOX) n = sphere_box(tmp, margin, p1, s1[0], p2, m2, s2);
       else if (u1 == SUMO_GEOM_CAPSULE && u2 == SUMO_GEOM_BOX) n = capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
       else n = 0; /* plane-box etc.: static-static, filtered at compile time */
+    }
+    {
+      int nact = 0;
+      for (int i = 0; i < n; i++) nact += tmp[i].dist < margin;
+      if (nact == 3) d->n_cb3++;
+      if (t2 == SUMO_GEOM_CYLINDER) { /* the rod's axis is the z axis of its frame, half length size[1] */
+        for (int i = 0; i < n; i++) {
+          if (!(tmp[i].dist < margin)) continue;
+          double d3[3] = {tmp[i].pos[0] - p2[0], tmp[i].pos[1] - p2[1], tmp[i].pos[2] - p2[2]}, ax[3] = {m2[2], m2[5], m2[8]};
+          if (fabs(dot3(d3, ax)) > s2[1]) d->n_rodcap++;
+        }
+      }
     }
     for (int i = 0; i < n; i++) {
       if (!(tmp[i].dist < margin)) continue; /* active iff dist < includemargin (gap = 0) */
@@ -1332,7 +1345,7 @@ int so_get_array(so_sim* s, int e, const char* name, double* out, int cap) {
 }
 
 int so_stats(const so_sim* s, double* o) {
-  for (int k = 0; k < 9; k++) o[k] = 0;
+  for (int k = 0; k < 11; k++) o[k] = 0;
   for (int e = 0; e < s->N; e++) {
     const env_t* d = s->env + e;
     o[0] += d->n_forward; o[1] += d->n_newton; o[2] += d->n_contacts; o[3] += d->n_efc;
@@ -1341,6 +1354,7 @@ int so_stats(const so_sim* s, double* o) {
     if (d->max_newton > o[6]) o[6] = d->max_newton;
     o[7] += d->ncon_dropped;
     o[8] += d->n_diverged;
+    o[9] += d->n_cb3; o[10] += d->n_rodcap;
   }
   return 0;
 }

@@ -37,7 +37,7 @@ int so_set_state(so_sim* s, const double* qpos, const double* qvel, const double
 int so_forward(so_sim* s, int e, const double* ctrl);       /* mj_forward at the env's current state */
 int so_mj_step(so_sim* s, int e, const double* ctrl, int n); /* n x mj_step (RK4) */
 int so_get_array(so_sim* s, int e, const char* name, double* out, int cap); /* returns count */
-int so_stats(const so_sim* s, double* out9); /* forward calls, newton iters, contacts, efc rows (totals); max ncon, max nefc, max newton iters, dropped contacts, diverged env steps */
+int so_stats(const so_sim* s, double* out11); /* forward calls, newton iters, contacts, efc rows (totals); max ncon, max nefc, max newton iters, dropped contacts, diverged env steps, capsule-box calls with 3 active contacts, rod contacts beyond the cylinder's flat end */
 int so_set_maxcon(so_sim* s, int maxcon);
 int so_set_jbcap(so_sim* s, int jbcap); /* capacity of the engine's Jacobian pool in halves (0 = unlimited) */
 int so_set_seeds(so_sim* s, const uint64_t* seeds);

@@ -12,7 +12,7 @@ from . import build as _build
 
 INFO_STRIDE = 8
 NDIMS = 16
-NSTATS = 11
+NSTATS = 13
 _LIB = None
 
 
@@ -194,7 +194,8 @@ class Engine:
         o = np.zeros(NSTATS)
         _chk(lib().sumo_stats(self.h, _np(o)))
         return dict(forward=o[0], newton=o[1], contacts=o[2], efc=o[3], max_ncon=o[4], max_nefc=o[5],
-                    max_newton=o[6], dropped=o[7], diverged=o[8], rollout_aborts=o[9], handover_mismatches=o[10])
+                    max_newton=o[6], dropped=o[7], diverged=o[8], rollout_aborts=o[9], handover_mismatches=o[10],
+                    capsule_box_3=o[11], rod_endcap=o[12])
 
     def rollout_status(self):
         """Waits for the engine's most recent fused rollout launch and RAISES if it was cut short (``sumo_rollout_status``:

@@ -435,6 +435,10 @@ struct Ctx {
   // statistics accumulated over the launch
   int st_forward, st_newton, st_ncon, st_nefc, st_maxcon, st_maxefc, st_maxnewton, st_dropped, st_dense, st_cross;
   int st_diverged;   // env steps of this launch whose state failed MuJoCo's bad-value test (state_is_bad)
+  // contact-generation fidelity accounting (deviations 1-2): capsule-box calls that produced 3 active contacts (MuJoCo's
+  // mjc_CapsuleBox gives at most 2) and active contacts on a border rod that lie beyond the cylinder's flat end (the rods collide
+  // as capsules: only there does the shape differ from MuJoCo's cylinder)
+  int st_cb3, st_rodcap;
   int hcross;
 };
 
@@ -1031,6 +1035,27 @@ __device__ __forceinline__ void collision(C& c) {
       int act[3], n = 0;
 #pragma unroll
       for (int q = 0; q < 3; q++) { act[q] = cs[q].ok && (cs[q].dist < margin); n += act[q]; }
+      {   // fidelity accounting (see Ctx::st_cb3): wave-uniform counts
+        c.st_cb3 += __popcll(__ballot(n == 3));
+        int nrod = 0;
+        if (n && k < ncand && b2 == 0) {
+          const int rc = prlist[k];
+          const int c2 = (rc >> 8) & 0xFF;
+          if (CTYPE(c2) == SUMO_GEOM_CAPSULE) {   // a world capsule is a border rod
+            const double* rp = S(xipos) + 3 * c2;
+            const double* ra = S(gaxis) + 3 * c2;
+            const double hl = CSIZE(c2)[1];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              const double d3[3] = {cs[q].pos[0] - rp[0], cs[q].pos[1] - rp[1], cs[q].pos[2] - rp[2]};
+              nrod += act[q] && fabs(dot3(d3, ra)) > hl;
+            }
+          }
+        }
+        int rtot;
+        (void)wave_excl_scan(nrod, lane, &rtot);
+        c.st_rodcap += rtot;
+      }
       int ctot, cbase = wave_excl_scan(n, lane, &ctot);
       int slot = ncon + cbase;
 #pragma unroll
@@ -2023,6 +2048,7 @@ __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.ncon = c.nlim = c.nefc = c.ndropped = c.use_prev = 0;
   c.st_forward = c.st_newton = c.st_ncon = c.st_nefc = c.st_maxcon = c.st_maxefc = c.st_maxnewton = c.st_dropped = c.st_dense = c.st_cross = 0;
   c.st_diverged = 0;
+  c.st_cb3 = c.st_rodcap = 0;
 #ifdef SUMO_PROFILE
   for (int k = 0; k < 24; k++) c.prof[k] = 0;
   c.tprev = clock64();
@@ -2082,6 +2108,8 @@ __device__ __forceinline__ void flush_stats(C& c, unsigned long long* stats) {
     atomicMax(stats + 6, (unsigned long long)c.st_maxnewton);
     atomicAdd(stats + 7, (unsigned long long)c.st_dropped);
     if (c.st_diverged) atomicAdd(stats + 8, (unsigned long long)c.st_diverged);
+    if (c.st_cb3) atomicAdd(stats + 11, (unsigned long long)c.st_cb3);
+    if (c.st_rodcap) atomicAdd(stats + 12, (unsigned long long)c.st_rodcap);
 #ifdef SUMO_PROFILE
     for (int k = 0; k < 24; k++) atomicAdd(stats + 16 + k, c.prof[k]);
 #endif

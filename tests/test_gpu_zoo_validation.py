@@ -56,8 +56,10 @@ def test_adjust_z_step_parity(env_id, tol):
         if lay:         # lay agent 0 of a few envs on the mat, legs folded up: z - 0.5 < 0.29 -> lost (would not be with adjust_z = 0)
             q, v, w, c = p.ora.get_state()
             q[:8, 2] = 0.76
+            q[:8, 3:7] = [1.0, 0.0, 0.0, 0.0]                     # upright, so that the folded legs do not reach the mat
             q[:8, 7:15] = [0.0, 1.0, 0.0, -1.0, 0.0, -1.0, 0.0, 1.0]
             v[:8] = 0.0
+            w[:8] = 0.0
             a[:8] = 0.0
             p.ora.set_state(q, v, w, c); p.eng.set_state(q, v, w, c)
         (gobs, ginfo, gdone, gr, gdr, gl), (oobs, oinfo, odone, orr, odr, ol) = p.step(a)
@@ -90,6 +92,10 @@ def test_set_adjust_z_on_vec_env_and_groups():
 
 
 KIN_BLOCKS = ("qpos", "qvel", "opp_qpos")
+# per-entry |sim mean - zoo mean| / zoo std allowed on the kinematic blocks.  'zero' feeds the nets zeros in the 84 contact-force
+# entries they were trained WITH (filter means there are far from 0), i.e. off-distribution input: they still fight and every
+# episode is decided, but gait and posture shift (measured: up to 0.59 sigma on one entry against 0.29 with the forces filled in)
+KIN_TOL = {"rne_post": 0.5, "zero": 0.75}
 # band of (sum of mean |force| entries, sim) / (the same, zoo file): see tests/test_zoo_validation.py -- bug: no free parameter;
 # ant / spider: the registry's densities (13 / 39) against the lighter agents the zoo was evidently trained on
 FORCE_BAND = {"ant": (1.05, 1.5), "bug": (0.88, 1.15), "spider": (1.3, 1.9)}
