@@ -394,9 +394,11 @@ def main():
             learner.begin_update(obs_b, ret_b, act_b, val_b, nlp_b, wts)
             for ep in range(nep):
                 inds = torch.randperm(nb, device=dev).to(torch.int32)      # device-side shuffle (np.random.shuffle in alg_ppo.py:375)
-                for start in range(0, nb, nb // nmb):
+                learner.prepare_epoch(inds, nb // nmb)     # multi-GPU: the epoch's advantage moments in one all-reduce (no-op on one GPU)
+                for k, start in enumerate(range(0, nb, nb // nmb)):
                     mb = inds[start:start + nb // nmb]
-                    learner.train_indexed(hp["lr"], hp["cliprange"], obs_b, ret_b, act_b, val_b, nlp_b, wts, mb, int(mb.numel()), sync=False)
+                    learner.train_indexed(hp["lr"], hp["cliprange"], obs_b, ret_b, act_b, val_b, nlp_b, wts, mb, int(mb.numel()), sync=False,
+                                          mb_index=k)
             learner.end_update()
             barrier()
             t_upd = time.perf_counter() - tu

@@ -182,6 +182,8 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
         elif update == 1:
             if not (recurrent and pool is not None):
                 runner.models[1].load(osp.join(checkdir, "00000"))
+            else:        # alg_ppo.py:208 loads 00000 into models[1]: the 'ours' selector of update 2 scores the opponent the rollout faced
+                opp_ref.load(osp.join(checkdir, "00000"))
             if pool is not None:
                 pool.set_snapshot(0, osp.join(checkdir, "00000"))
                 pool.assign_round_robin([0])
@@ -274,11 +276,15 @@ def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_d
             nmb_steps = sdist.agree_max(nmb_steps, comm, device=dev)
         for epoch in range(noptepochs if not recurrent else 0):
             inds = torch.randperm(nsamp, device=dev, generator=shuffle_gen).to(torch.int32)   # np.random.shuffle (:375), on the device
+            if comm is not None and hasattr(model, "prepare_epoch"):
+                # equal shards: the advantage moments of all the epoch's minibatches in ONE all-reduce, so that every optimiser step
+                # issues exactly one collective; a no-op with opponent-data reuse (unequal shards)
+                model.prepare_epoch(inds, nbatch_train)
             for ii in range(nmb_steps):
                 mb = inds[ii * nbatch_train:(ii + 1) * nbatch_train]       # empty once this rank's rows are used up
                 # statistics stay on the device unless the KL early stop needs them now (alg_ppo.py:389-398)
                 out = model.train_indexed(lrnow, cliprangenow, b_obs, b_ret, b_act, b_val, b_nlp, weights, mb, int(mb.numel()),
-                                          sync=kl_threshold is not None)
+                                          sync=kl_threshold is not None, mb_index=ii)
                 mblossvals.append(out[:5] if kl_threshold is not None else out)
                 if kl_threshold is not None and out[3] > kl_threshold * 1.5:
                     early_stop, stop_info = True, [epoch, ii]

@@ -1,11 +1,12 @@
 // ppo_kernels.hip -- MI355X (gfx950) kernels for the PPO2 self-play rollout / update arithmetic (include/sumo_ppo.h).
 //
 // Dense layers run on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact f32, so results stay comparable with
-// the reference's float32 TF graph).  One wavefront owns a 16-row tile of the batch: activations of the tile live in
+// the reference's float32 TF graph).  Inference: one wavefront owns a 16-row tile of the batch, activations of the tile live in
 // LDS (row stride == 2 mod 32 floats -> conflict-free A-operand reads), weights are read straight from L2 as B
-// operands (24.5 k parameters, resident), weight gradients accumulate in MFMA accumulator registers across all tiles a
-// wave processes and are written once as a per-wave slab that a second kernel reduces in a fixed order (deterministic,
-// no float atomics).
+// operands (24.5 k parameters, resident).  Training (ppo_grad_kernel): four waves share a tile, each owning 16 hidden units with
+// its weight slices resident in registers; weight gradients accumulate in MFMA accumulator registers across all tiles of a
+// workgroup and are written once as a per-workgroup slab that a second kernel reduces in a fixed order (deterministic, no float
+// atomics).
 //
 // Reference arithmetic reproduced: policies.py:14-128 / baselines models.py:74-103 / distributions.py:227-251 (forward),
 // model.py:65-139 (loss, gradient clipping, Adam), model.py:180-185 (advantage normalisation), runner.py:127-143,166-196
@@ -1347,236 +1348,242 @@ struct GradArgs {
   ParamLayout L;
 };
 
-// dW[KT x 4 tiles] += Act^T[features x rows] * Delta[rows x 64]: act/delta tiles in LDS, row-major [16][stride]
-template <int KT>
-__device__ __forceinline__ void accumulate_wgrad(f32x4 (&acc)[KT][4], const float* act, int astride, const float* delta, int lane) {
-  const int i = lane & 15, kq = lane >> 4;
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    int row = 4 * s + kq;
-    float b[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ct++) b[ct] = delta[row * HS + ct * 16 + i];
-#pragma unroll
-    for (int ft = 0; ft < KT; ft++) {
-      float a = act[row * astride + ft * 16 + i];
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[ft][ct] = MFMA(a, b[ct], acc[ft][ct]);
-    }
-  }
-}
-
-// delta_in[16][HS] (LDS) times W^T -> masked by act > 0 -> delta_out (LDS); W is [64 x 64] row-major [in][out],
-// so (delta W^T)[row][f] = sum_k delta[row][k] * W[f][k].  Also accumulates the column sums of the result (bias grad).
-__device__ __forceinline__ void backprop_hidden(const float* delta_in, const float* W, const float* act, float* delta_out, float (&bsum)[4],
-                                                int lane) {
-  const int i = lane & 15, kq = lane >> 4;
-  f32x4 acc[4];
-#pragma unroll
-  for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
-  {  // all 64 weight loads in flight before the first product (see trunk_forward)
-    float b[H / 4][4];
-#pragma unroll
-    for (int u = 0; u < H / 4; u++)
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) b[u][ct] = W[(ct * 16 + i) * H + 4 * u + kq];
-#pragma unroll
-    for (int u = 0; u < H / 4; u++) {
-      const float a = delta_in[i * HS + 4 * u + kq];
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(a, b[u][ct], acc[ct]);
-    }
-  }
-#pragma unroll
-  for (int ct = 0; ct < 4; ct++) {
-    float s = 0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      int o = (4 * kq + r) * HS + ct * 16 + i;
-      float d = act[o] > 0.0f ? acc[ct][r] : 0.0f;
-      delta_out[o] = d;
-      s += d;
-    }
-    bsum[ct] += s;
-  }
-}
-
+// ---------------------------------------------------------------------------------------------------------
+// Gradient kernel: FOUR waves share a 16-row tile; wave w owns the hidden units 16w .. 16w+15 of both hidden layers.
+//   * the wave's slices of every weight matrix it multiplies by -- W0[:, slice], W1[:, slice], W1[slice, :]^T, W2 (head) and
+//     W2[slice, :]^T -- stay in registers as MFMA B operands for the whole launch: no weight load inside the tile loop;
+//   * activations and deltas cross the waves through one set of LDS tiles (four block barriers per tile);
+//   * the wave accumulates ITS columns of the weight gradients (gW0[:, slice], gW1[:, slice]; rows 16w.. of gW2) in MFMA
+//     accumulators over all tiles of the block and the block writes ONE slab at the end (a quarter of the slab traffic of the
+//     wave-per-tile form, a quarter of its per-tile dependent chain: 133 instead of 484 MFMAs per tile and wave);
+//   * the next tile's rows are requested (gathered through idx) before the backward half and committed to the other half of a
+//     double-buffered observation tile after it.
+// The head (16 MFMAs) and the loss deltas are evaluated redundantly by every wave -- cheaper than a fifth barrier with three
+// waves idle -- and only wave 0 keeps the statistics, the head-bias and the logstd gradients.
+// (round 2's kernel: one wave per tile with the whole gradient of a net in its accumulators, 110 us per 16 384-row minibatch)
+// ---------------------------------------------------------------------------------------------------------
 template <int KT, bool PI>
-__device__ __forceinline__ void grad_net(const GradArgs& a, float* lds, int wave_global, int lane) {
+__device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int lane, int w) {
   const ParamLayout& L = a.L;
   const int XS = a.XS, D = L.D, A = L.A;
-  const int i = lane & 15, kq = lane >> 4;
-  float *xbuf = lds, *h1 = xbuf + 16 * XS, *h2 = h1 + 16 * HS, *d1 = h2 + 16 * HS, *d2 = d1 + 16 * HS, *dout = d2 + 16 * HS;
+  const int i = lane & 15, kq = lane >> 4, tid = threadIdx.x;
+  constexpr int K0 = 4 * KT;   // k-steps of the first layer (four features per step)
+  float *xb0 = lds, *xb1 = xb0 + 16 * XS, *h1 = xb1 + 16 * XS, *h2 = h1 + 16 * HS, *d1 = h2 + 16 * HS, *d2 = d1 + 16 * HS;
+  float* mydout = d2 + 16 * HS + w * 16 * 18;   // this wave's copy of the head deltas [16][18]
   const Net net = PI ? pi_net(a.params, L) : vf_net(a.params, L);
-  f32x4 gW0[KT][4], gW1[4][4], gW2[4][1];
-#pragma unroll
-  for (int ft = 0; ft < KT; ft++)
-#pragma unroll
-    for (int ct = 0; ct < 4; ct++) gW0[ft][ct] = (f32x4){0, 0, 0, 0};
-#pragma unroll
-  for (int ft = 0; ft < 4; ft++) {
-#pragma unroll
-    for (int ct = 0; ct < 4; ct++) gW1[ft][ct] = (f32x4){0, 0, 0, 0};
-    gW2[ft][0] = (f32x4){0, 0, 0, 0};
-  }
-  float gb0[4] = {0, 0, 0, 0}, gb1[4] = {0, 0, 0, 0}, gb2 = 0, glogstd = 0;
-  double st_pg = 0, st_vf = 0, st_kl = 0, st_clip = 0, st_cnt = 0;
+  const int cw = 16 * w + i;   // the hidden unit this lane's column stands for
   const bool col = i < net.nout;
+  // ---- resident B operands (lane (i, kq) holds B[k = 4u + kq][column i] of k-step u)
+  float bW0[K0], bW1[16], bW1T[16], bW2[16], bW2T[4];
+#pragma unroll
+  for (int u = 0; u < K0; u++) { const int k = 4 * u + kq; const float v = net.w0[(k < D ? k : D - 1) * H + cw]; bW0[u] = k < D ? v : 0.0f; }
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    bW1[u] = net.w1[(4 * u + kq) * H + cw];
+    bW1T[u] = net.w1[cw * H + 4 * u + kq];                                   // (delta W1^T)[row][f] = sum_k delta[row][k] W1[f][k]
+    const float v = net.w2[(4 * u + kq) * net.nout + (col ? i : 0)];
+    bW2[u] = col ? v : 0.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int k = 4 * u + kq; const float v = net.w2[cw * net.nout + (k < net.nout ? k : 0)]; bW2T[u] = k < net.nout ? v : 0.0f; }
+  const float bias0 = net.b0[cw], bias1 = net.b1[cw];
+  const float bias2 = col ? net.b2[i] : 0.0f;
+  f32x4 gW0[KT], gW1[4], gW2 = (f32x4){0, 0, 0, 0};
+#pragma unroll
+  for (int ft = 0; ft < KT; ft++) gW0[ft] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+  for (int ft = 0; ft < 4; ft++) gW1[ft] = (f32x4){0, 0, 0, 0};
+  float gb0 = 0, gb1 = 0, gb2 = 0, glogstd = 0;
+  double st_pg = 0, st_vf = 0, st_kl = 0, st_clip = 0, st_cnt = 0;
   const float logstd = (PI && col) ? a.params[L.logstd + i] : 0.0f;
   const float std = expf(logstd);
   const float sum_logstd = row16_sum(logstd);
   const int ntiles = (a.n + 15) / 16;
-  for (int tile = wave_global; tile < ntiles; tile += a.nwaves) {
+  // ---- observation rows: thread (row = tid / 16, c = tid % 16 + 16 j) -- 16 threads read a row in 64-byte pieces
+  const int xr = tid >> 4, xc = tid & 15;
+  constexpr int NXJ = KT;   // 16 * KT columns cover D
+  float xv[NXJ];
+  auto request = [&](int tile) {
+    const int row = tile * 16 + xr;
+    const bool rok = tile < ntiles && row < a.n;
+    const int src = rok ? (a.idx ? a.idx[row] : row) : 0;
+    const float* orow = a.obs + (size_t)src * a.obs_stride;
+#pragma unroll
+    for (int j = 0; j < NXJ; j++) { const int c = xc + 16 * j; const float v = orow[c < D ? c : D - 1]; xv[j] = (rok && c < D) ? v : 0.0f; }
+  };
+  auto commit = [&](float* xb) {   // columns D .. 16 KT - 1 are written as zeros (the launch sizes the row stride for the variant: XS >= 16 KT)
+#pragma unroll
+    for (int j = 0; j < NXJ; j++) xb[xr * XS + xc + 16 * j] = xv[j];
+  };
+  int tile = blockIdx.x;
+  request(tile);
+  commit(xb0);
+  __syncthreads();
+  for (int it = 0; tile < ntiles; tile += gridDim.x, it++) {
+    float* xbuf = (it & 1) ? xb1 : xb0;
     const int r0 = tile * 16;
-    stage_x(xbuf, XS, a.obs, a.obs_stride, D, a.idx, r0, a.n, lane);
-    wave_sync();
-    f32x4 out = trunk_forward(net, xbuf, XS, D, h1, h2, lane);
-    // ---- head deltas (D layout: rows 4kq+r, column i)
+    // ---- first layer, this wave's 16 units: two accumulation chains over the even / odd k-steps
+    f32x4 acc = (f32x4){0, 0, 0, 0}, acc2 = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < K0; u += 2) {
+      acc = MFMA(xbuf[i * XS + 4 * u + kq], bW0[u], acc);
+      acc2 = MFMA(xbuf[i * XS + 4 * u + 4 + kq], bW0[u + 1], acc2);
+    }
+    float h1v[4], h2v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { h1v[r] = fmaxf(acc[r] + acc2[r] + bias0, 0.0f); h1[(4 * kq + r) * HS + cw] = h1v[r]; }
+    __syncthreads();
+    // ---- second layer
+    acc = (f32x4){0, 0, 0, 0}; acc2 = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+      acc = MFMA(h1[i * HS + 4 * u + kq], bW1[u], acc);
+      acc2 = MFMA(h1[i * HS + 4 * u + 4 + kq], bW1[u + 1], acc2);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { h2v[r] = fmaxf(acc[r] + acc2[r] + bias1, 0.0f); h2[(4 * kq + r) * HS + cw] = h2v[r]; }
+    __syncthreads();
+    request(tile + gridDim.x);   // the next tile's rows travel during the head and the backward half
+    // ---- head (every wave) + loss deltas (D layout: rows 4kq+r, column i)
+    f32x4 out = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 16; u++) out = MFMA(h2[i * HS + 4 * u + kq], bW2[u], out);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      int row = r0 + 4 * kq + r;
-      bool rok = row < a.n;
-      int src = rok ? (a.idx ? a.idx[row] : row) : 0;
+      const int row = r0 + 4 * kq + r;
+      const bool rok = row < a.n;
+      const int src = rok ? (a.idx ? a.idx[row] : row) : 0;
       float dhead = 0.0f;
       if (PI) {
-        float m = out[r];
-        float act = (rok && col) ? a.actions[(size_t)src * A + i] : m;
+        const float m = out[r] + bias2;
+        const float act = (rok && col) ? a.actions[(size_t)src * A + i] : m;
         float z = (act - m) / std;
         if (!(rok && col)) z = 0.0f;
-        float ss = row16_sum(z * z);
-        float nlp = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
-        float old = rok ? a.oldnlp[src] : nlp;
-        float lr = old - nlp;
+        const float ss = row16_sum(z * z);
+        const float nlp = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
+        const float old = rok ? a.oldnlp[src] : nlp;
+        const float lr = old - nlp;
         float ratio = expf(lr);
-        bool isnan_ = ratio != ratio;
+        const bool isnan_ = ratio != ratio;
         if (isnan_) ratio = 2.0f;                                         // model.py:96
-        float adv = rok ? a.adv[row] : 0.0f, w = rok ? a.weight[src] : 0.0f;
-        float lo = 1.0f - a.cliprange, hi = 1.0f + a.cliprange;
-        float rc = fminf(fmaxf(ratio, lo), hi);
-        float l1 = -adv * ratio, l2 = -adv * rc;
-        bool first = l1 >= l2;
-        bool in_clip = ratio >= lo && ratio <= hi;
-        float dratio = w * a.inv_count * (first ? -adv : (in_clip ? -adv : 0.0f));
+        const float adv = rok ? a.adv[row] : 0.0f, wt = rok ? a.weight[src] : 0.0f;
+        const float lo = 1.0f - a.cliprange, hi = 1.0f + a.cliprange;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float l1 = -adv * ratio, l2 = -adv * rc;
+        const bool first = l1 >= l2;
+        const bool in_clip = ratio >= lo && ratio <= hi;
+        float dratio = wt * a.inv_count * (first ? -adv : (in_clip ? -adv : 0.0f));
         if (isnan_) dratio = 0.0f;
-        float dnlp = -dratio * ratio;
+        const float dnlp = -dratio * ratio;
         dhead = col ? dnlp * (-(z / std)) : 0.0f;
         if (rok && col) glogstd += dnlp * (1.0f - z * z) - a.ent_coef * a.inv_count;
-        if (rok && i == 0) {
-          st_pg += (double)(w * fmaxf(l1, l2));
+        if (w == 0 && rok && i == 0) {
+          st_pg += (double)(wt * fmaxf(l1, l2));
           st_kl += (double)(nlp - old);
           st_clip += (fabsf(ratio - 1.0f) > a.cliprange) ? 1.0 : 0.0;
           st_cnt += 1.0;
           if (a.log_ratio) a.log_ratio[row] = lr;
         }
       } else {
-        float v = out[r];
-        float R = rok ? a.returns[src] : v;
-        float dv = v - R;
+        const float v = out[r] + bias2;
+        const float R = rok ? a.returns[src] : v;
+        const float dv = v - R;
         dhead = (rok && col) ? a.vf_coef * a.inv_count * dv : 0.0f;
-        if (rok && i == 0) { st_vf += 0.5 * (double)dv * (double)dv; st_cnt += 1.0; }
+        if (w == 0 && rok && i == 0) { st_vf += 0.5 * (double)dv * (double)dv; st_cnt += 1.0; }
       }
-      dout[(4 * kq + r) * 18 + i] = dhead;
+      mydout[(4 * kq + r) * 18 + i] = dhead;
       gb2 += dhead;
     }
     wave_sync();
-    // ---- head weight gradient: gW2[64 x nout] += h2^T * dhead  (B operand = dhead tile, 16 columns)
+    // ---- head weight gradient, rows 16w .. 16w+15: gW2 += h2[:, slice]^T dhead
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      int row = 4 * s + kq;
-      float b = dout[row * 18 + i];
-#pragma unroll
-      for (int ft = 0; ft < 4; ft++) gW2[ft][0] = MFMA(h2[row * HS + ft * 16 + i], b, gW2[ft][0]);
-    }
-    // ---- dh2 = dhead * W2^T, masked by h2 > 0
+    for (int s_ = 0; s_ < 4; s_++) { const int row = 4 * s_ + kq; gW2 = MFMA(h2[row * HS + cw], mydout[row * 18 + i], gW2); }
+    // ---- dh2[:, slice] = dhead W2[slice, :]^T, masked by h2 > 0
+    acc = (f32x4){0, 0, 0, 0};
     {
-      f32x4 acc[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[ct] = (f32x4){0, 0, 0, 0};
-      const int nk = (net.nout + 3) & ~3;
-      float bw[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int k = 4 * u + kq;
-        const bool kok = k < net.nout;
-#pragma unroll
-        for (int ct = 0; ct < 4; ct++) bw[u][ct] = kok ? net.w2[(ct * 16 + i) * net.nout + k] : 0.0f;
-      }
+      const int nk = (net.nout + 3) >> 2;
 #pragma unroll
       for (int u = 0; u < 4; u++)
-        if (4 * u < nk) {
-          const float av = dout[i * 18 + 4 * u + kq];
-#pragma unroll
-          for (int ct = 0; ct < 4; ct++) acc[ct] = MFMA(av, bw[u][ct], acc[ct]);
-        }
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) {
-        float s = 0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          int o = (4 * kq + r) * HS + ct * 16 + i;
-          float d = h2[o] > 0.0f ? acc[ct][r] : 0.0f;
-          d2[o] = d;
-          s += d;
-        }
-        gb1[ct] += s;
-      }
+        if (u < nk) acc = MFMA(mydout[i * 18 + 4 * u + kq], bW2T[u], acc);
     }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const float d = h2v[r] > 0.0f ? acc[r] : 0.0f; d2[(4 * kq + r) * HS + cw] = d; gb1 += d; }
+    __syncthreads();
+    // ---- gW1[:, slice] += h1^T d2[:, slice]
+#pragma unroll
+    for (int s_ = 0; s_ < 4; s_++) {
+      const int row = 4 * s_ + kq;
+      const float b = d2[row * HS + cw];
+#pragma unroll
+      for (int ft = 0; ft < 4; ft++) gW1[ft] = MFMA(h1[row * HS + ft * 16 + i], b, gW1[ft]);
+    }
+    // ---- dh1[:, slice] = d2 W1[slice, :]^T, masked by h1 > 0 (only this wave reads its slice of d1 back)
+    acc = (f32x4){0, 0, 0, 0}; acc2 = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+      acc = MFMA(d2[i * HS + 4 * u + kq], bW1T[u], acc);
+      acc2 = MFMA(d2[i * HS + 4 * u + 4 + kq], bW1T[u + 1], acc2);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const float d = h1v[r] > 0.0f ? acc[r] + acc2[r] : 0.0f; d1[(4 * kq + r) * HS + cw] = d; gb0 += d; }
     wave_sync();
-    accumulate_wgrad<4>(gW1, h1, HS, d2, lane);
-    backprop_hidden(d2, net.w1, h1, d1, gb0, lane);
-    wave_sync();
-    accumulate_wgrad<KT>(gW0, xbuf, XS, d1, lane);
-    wave_sync();
+    // ---- gW0[:, slice] += x^T d1[:, slice]
+#pragma unroll
+    for (int s_ = 0; s_ < 4; s_++) {
+      const int row = 4 * s_ + kq;
+      const float b = d1[row * HS + cw];
+#pragma unroll
+      for (int ft = 0; ft < KT; ft++) gW0[ft] = MFMA(xbuf[row * XS + ft * 16 + i], b, gW0[ft]);
+    }
+    commit((it & 1) ? xb0 : xb1);
+    __syncthreads();   // the tile's buffers are free again, the next tile's rows are in place
   }
-  // ---- write this wave's partial gradients (slab) -- D layout: rows 4kq+r of the tile, column i
-  float* slab = a.slabs + ((size_t)(PI ? 0 : 1) * a.nwaves + wave_global) * L.P;
+  // ---- this block's partial gradients (slab) -- D layout: rows 4kq+r of the tile, column i
+  float* slab = a.slabs + ((size_t)(PI ? 0 : 1) * a.nwaves + blockIdx.x) * L.P;
   const int o_w0 = PI ? L.pi_w0 : L.vf_w0, o_b0 = PI ? L.pi_b0 : L.vf_b0, o_w1 = PI ? L.pi_w1 : L.vf_w1, o_b1 = PI ? L.pi_b1 : L.vf_b1;
   const int o_w2 = PI ? L.pi_w : L.vf_w, o_b2 = PI ? L.pi_b : L.vf_b;
 #pragma unroll
   for (int ft = 0; ft < KT; ft++)
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++)
+    for (int r = 0; r < 4; r++) {
+      const int f = ft * 16 + 4 * kq + r;
+      if (f < D) slab[o_w0 + f * H + cw] = gW0[ft][r];
+    }
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        int f = ft * 16 + 4 * kq + r;
-        if (f < D) slab[o_w0 + f * H + ct * 16 + i] = gW0[ft][ct][r];
-      }
+  for (int ft = 0; ft < 4; ft++)
 #pragma unroll
-  for (int ft = 0; ft < 4; ft++) {
+    for (int r = 0; r < 4; r++) slab[o_w1 + (ft * 16 + 4 * kq + r) * H + cw] = gW1[ft][r];
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) slab[o_w1 + (ft * 16 + 4 * kq + r) * H + ct * 16 + i] = gW1[ft][ct][r];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-      if (col) slab[o_w2 + (ft * 16 + 4 * kq + r) * net.nout + i] = gW2[ft][0][r];
+  for (int r = 0; r < 4; r++)
+    if (col) slab[o_w2 + (16 * w + 4 * kq + r) * net.nout + i] = gW2[r];
+  {
+    const float s0 = kq_sum(gb0), s1 = kq_sum(gb1);
+    if (kq == 0) { slab[o_b0 + cw] = s0; slab[o_b1 + cw] = s1; }
   }
-#pragma unroll
-  for (int ct = 0; ct < 4; ct++) {
-    float s0 = kq_sum(gb0[ct]), s1 = kq_sum(gb1[ct]);
-    if (kq == 0) { slab[o_b0 + ct * 16 + i] = s0; slab[o_b1 + ct * 16 + i] = s1; }
-  }
-  float s2 = kq_sum(gb2), sl = kq_sum(glogstd);
-  if (kq == 0 && col) { slab[o_b2 + i] = s2; if (PI) slab[L.logstd + i] = sl; }
-  // stats: lanes with i == 0 hold per-kq partials
-  double t_pg = st_pg, t_vf = st_vf, t_kl = st_kl, t_clip = st_clip, t_cnt = st_cnt;
-  for (int o = 16; o < 64; o <<= 1) {
-    t_pg += __shfl_xor(t_pg, o, WAVE); t_vf += __shfl_xor(t_vf, o, WAVE); t_kl += __shfl_xor(t_kl, o, WAVE);
-    t_clip += __shfl_xor(t_clip, o, WAVE); t_cnt += __shfl_xor(t_cnt, o, WAVE);
-  }
-  if (lane == 0) {
-    double* ws = a.wstats + ((size_t)(PI ? 0 : 1) * a.nwaves + wave_global) * 8;
-    ws[0] = t_pg; ws[1] = t_vf; ws[2] = 0; ws[3] = t_kl; ws[4] = t_clip; ws[5] = 0; ws[6] = PI ? t_cnt : 0.0; ws[7] = 0;
+  if (w == 0) {
+    const float s2 = kq_sum(gb2), sl = kq_sum(glogstd);
+    if (kq == 0 && col) { slab[o_b2 + i] = s2; if (PI) slab[L.logstd + i] = sl; }
+    // stats: lanes with i == 0 hold per-kq partials
+    double t_pg = st_pg, t_vf = st_vf, t_kl = st_kl, t_clip = st_clip, t_cnt = st_cnt;
+    for (int o = 16; o < 64; o <<= 1) {
+      t_pg += __shfl_xor(t_pg, o, WAVE); t_vf += __shfl_xor(t_vf, o, WAVE); t_kl += __shfl_xor(t_kl, o, WAVE);
+      t_clip += __shfl_xor(t_clip, o, WAVE); t_cnt += __shfl_xor(t_cnt, o, WAVE);
+    }
+    if (lane == 0) {
+      double* ws = a.wstats + ((size_t)(PI ? 0 : 1) * a.nwaves + blockIdx.x) * 8;
+      ws[0] = t_pg; ws[1] = t_vf; ws[2] = 0; ws[3] = t_kl; ws[4] = t_clip; ws[5] = 0; ws[6] = PI ? t_cnt : 0.0; ws[7] = 0;
+    }
   }
 }
 
+#define GRAD_LDS_FLOATS(XS) (2 * 16 * (XS) + 4 * 16 * HS + 4 * 16 * 18)
+// Ant (KT = 8): 255 registers, two workgroups per CU.  The wider first layers of the Bug / Spider nets (KT = 11 / 14: 44 / 56 resident
+// B operands and as many accumulators) get the whole register file of a SIMD instead of spilling: one workgroup per CU.
 template <int KT>
-__global__ void __launch_bounds__(256) ppo_grad_kernel(GradArgs a) {
+__global__ void __launch_bounds__(256, (KT <= 8 ? 2 : 1)) ppo_grad_kernel(GradArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wave_global = blockIdx.x * 4 + wid;
-  float* lds = smem_f + wid * (16 * a.XS + 4 * 16 * HS + 16 * 18);
-  if (blockIdx.y == 0) grad_net<KT, true>(a, lds, wave_global, lane);
-  else grad_net<KT, false>(a, lds, wave_global, lane);
+  if (blockIdx.y == 0) grad_net_coop<KT, true>(a, smem_f, lane, wid);
+  else grad_net_coop<KT, false>(a, smem_f, lane, wid);
 }
 
 // grads[p] = sum over waves of the slab of the net that owns p; stats += per-wave stats.  Two passes so that the 100 MB of
@@ -1620,7 +1627,7 @@ __global__ void __launch_bounds__(256) ppo_grad_reduce2_kernel(const float* part
   }
 }
 
-static int grad_nwaves(void) { return 256 * 4; }
+static int grad_nwaves(void) { return 256 * 4; }   // slabs per net the workspace is sized for
 extern "C" size_t ppo_grad_workspace_bytes(int ob_dim, int ac_dim) {
   ParamLayout L = make_layout(ob_dim, ac_dim);
   return (size_t)2 * grad_nwaves() * L.P * sizeof(float) + (size_t)2 * grad_nwaves() * 8 * sizeof(double) +
@@ -1638,21 +1645,23 @@ extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, i
   if (KT > 14) FAIL(-3, "ob_dim %d too large (max 224)", ob_dim);
   GradArgs a;
   a.params = params; a.obs = obs; a.actions = actions; a.adv = adv_mb; a.returns = returns; a.oldnlp = old_neglogp; a.weight = is_weight;
-  a.idx = idx; a.n = n; a.obs_stride = obs_stride; a.XS = x_stride(ob_dim); a.inv_count = (float)inv_count; a.cliprange = cliprange;
+  // the staged tile has the variant's full width (16 KT columns, zeros beyond ob_dim): no guards inside the tile loop
+  a.idx = idx; a.n = n; a.obs_stride = obs_stride; a.XS = x_stride(16 * (KT <= 8 ? 8 : (KT <= 11 ? 11 : 14))); a.inv_count = (float)inv_count; a.cliprange = cliprange;
   a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.log_ratio = log_ratio_out; a.L = make_layout(ob_dim, ac_dim);
   int ntiles = (n + 15) / 16;
-  int nblocks = (ntiles + 3) / 4;
-  {  // 128 blocks (two 16-row tiles per wave at 16384 rows) halve the slab traffic of one tile per wave: 268 vs 317 us per SGD step
+  int nblocks = ntiles;      // workgroups per net; a workgroup (4 waves) takes the tiles blockIdx.x, blockIdx.x + nblocks, ...
+  {  // default 256 per net = two resident workgroups per CU over both nets: every workgroup writes one slab (P/2 floats), so more of
+     // them shorten the tile loops but lengthen the slab reduction
     const char* nbc = getenv("PPO_GRAD_BLOCKS");
-    int cap = nbc ? atoi(nbc) : 128;
+    int cap = nbc ? atoi(nbc) : 256;
     if (cap < 1) cap = 1;
-    if (cap > 256) cap = 256;   // the workspace is sized for 256 blocks (grad_nwaves)
+    if (cap > grad_nwaves()) cap = grad_nwaves();   // the workspace holds grad_nwaves() slabs per net
     if (nblocks > cap) nblocks = cap;
   }
-  a.nwaves = nblocks * 4;
+  a.nwaves = nblocks;        // slabs (and statistics records) per net
   a.slabs = (float*)workspace;
   a.wstats = (double*)((char*)workspace + (size_t)2 * grad_nwaves() * a.L.P * sizeof(float));
-  size_t lds = (size_t)4 * (16 * a.XS + 4 * 16 * HS + 16 * 18) * sizeof(float);
+  size_t lds = (size_t)GRAD_LDS_FLOATS(a.XS) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   // the slabs are only partially written by each net (its own ranges); the reduce reads only those ranges
 #define LAUNCH(KTV)                                                                                                     \
@@ -1666,7 +1675,7 @@ extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, i
   } while (0)
   if (KT <= 8) LAUNCH(8);
   else if (KT <= 11) LAUNCH(11);
-  else LAUNCH(14);
+  else LAUNCH(14);   // (the tile's 16 KT staged columns must fit its LDS row: x_stride(D) >= 16 KT for every D of a variant)
 #undef LAUNCH
   HIPCHK(hipGetLastError());
   {

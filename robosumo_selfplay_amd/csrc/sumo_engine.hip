@@ -304,6 +304,34 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
   return inc - v;
 }
 
+// Contact-generation fidelity accounting, once per forward evaluation and OUT OF LINE (its own register allocation; the hot loops
+// of the collision phase are not touched): among the `ncon` contacts just stored (cond [14 per contact]: dist, pos[3], frame[9], -;
+// cb [4 per contact]: body1, body2, pair, -) counts
+//   * capsule-box calls that produced three active contacts -- three consecutive contacts of one pair (only capsule-box yields
+//     three; MuJoCo's mjc_CapsuleBox at most two) -- low 16 bits;
+//   * contacts on a border rod (a world CYLINDER, collided as a capsule) that lie beyond the cylinder's flat end, i.e. on the
+//     capsule's end cap, the only place where the two shapes differ -- high 16 bits.
+__device__ __noinline__ int fidelity_count(const double* cond, const int* cb, int ncon, int lane, const int32_t PT_GAS* pair_geom2,
+                                           const int32_t PT_GAS* geom_type, const double PT_GAS* geom_pos, const double PT_GAS* geom_quat,
+                                           const double PT_GAS* geom_size) {
+  int cb3 = 0, rod = 0;
+  if (lane < ncon) {
+    const int p = cb[4 * lane + 2];
+    if (lane + 2 < ncon && cb[4 * (lane + 1) + 2] == p && cb[4 * (lane + 2) + 2] == p) cb3 = 1;
+    if (cb[4 * lane + 1] == 0) {   // the second body is the world
+      const int g2 = pair_geom2[p];
+      if (geom_type[g2] == SUMO_GEOM_CYLINDER) {
+        const double w = geom_quat[4 * g2], x = geom_quat[4 * g2 + 1], y = geom_quat[4 * g2 + 2], z = geom_quat[4 * g2 + 3];
+        const double ax[3] = {2 * (x * z + w * y), 2 * (y * z - w * x), w * w - x * x - y * y + z * z};   // the rod's axis: z column of its frame
+        const double d = (cond[14 * lane + 1] - geom_pos[3 * g2]) * ax[0] + (cond[14 * lane + 2] - geom_pos[3 * g2 + 1]) * ax[1] +
+                         (cond[14 * lane + 3] - geom_pos[3 * g2 + 2]) * ax[2];
+        rod = fabs(d) > geom_size[3 * g2 + 1];
+      }
+    }
+  }
+  return __popcll(__ballot(cb3)) | (__popcll(__ballot(rod)) << 16);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // narrow phase primitives.  A lane produces up to 3 contacts {dist, pos, normal} in registers.
 // ---------------------------------------------------------------------------------------------------------
@@ -1035,27 +1063,6 @@ __device__ __forceinline__ void collision(C& c) {
       int act[3], n = 0;
 #pragma unroll
       for (int q = 0; q < 3; q++) { act[q] = cs[q].ok && (cs[q].dist < margin); n += act[q]; }
-      {   // fidelity accounting (see Ctx::st_cb3): wave-uniform counts
-        c.st_cb3 += __popcll(__ballot(n == 3));
-        int nrod = 0;
-        if (n && k < ncand && b2 == 0) {
-          const int rc = prlist[k];
-          const int c2 = (rc >> 8) & 0xFF;
-          if (CTYPE(c2) == SUMO_GEOM_CAPSULE) {   // a world capsule is a border rod
-            const double* rp = S(xipos) + 3 * c2;
-            const double* ra = S(gaxis) + 3 * c2;
-            const double hl = CSIZE(c2)[1];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-              const double d3[3] = {cs[q].pos[0] - rp[0], cs[q].pos[1] - rp[1], cs[q].pos[2] - rp[2]};
-              nrod += act[q] && fabs(dot3(d3, ra)) > hl;
-            }
-          }
-        }
-        int rtot;
-        (void)wave_excl_scan(nrod, lane, &rtot);
-        c.st_rodcap += rtot;
-      }
       int ctot, cbase = wave_excl_scan(n, lane, &ctot);
       int slot = ncon + cbase;
 #pragma unroll
@@ -1084,6 +1091,14 @@ __device__ __forceinline__ void collision(C& c) {
   c.ncon = ncon;
   c.ndropped = dropped;
   SYNC();
+#ifndef SUMO_NO_FIDELITY
+  {   // contact-generation fidelity accounting (Ctx::st_cb3), out of line: the narrow-phase loop above stays as it was
+    const sumo_model_t& mdl = c.P->mdl;
+    const int r = fidelity_count(S(cond), c.si + c.L.con_b, ncon, lane, MI(pair_geom2), MI(geom_type), MF(geom_pos), MF(geom_quat), MF(geom_size));
+    c.st_cb3 += r & 0xFFFF;
+    c.st_rodcap += r >> 16;
+  }
+#endif
 }
 
 // ---- constraint rows -----------------------------------------------------------------------------------------

@@ -45,6 +45,7 @@ class PPOModel(object):
             self.workspace = torch.empty(ppo_capi.lib().ppo_grad_workspace_bytes(D, A), dtype=torch.uint8, device=self.device)
             self._graphs = {}
             self._static = None
+            self._epoch_moments = None
 
     # ---- checkpoints: list of 13 float32 arrays in TF variable order (model.py:153-177) -----------------------
     def get_param_list(self):
@@ -97,17 +98,62 @@ class PPOModel(object):
     use_graph = os.environ.get("SUMO_PPO_GRAPH", "1") != "0"
     equal_counts = True   # multi-GPU: minibatches have the same size on every rank (learn() clears it for opponent-data reuse)
 
-    def _launch_loss_grad(self, obs, returns, actions, values, neglogpacs, weights, idx, n, cliprange, adv, log_ratio, st):
+    def _launch_loss_grad(self, obs, returns, actions, values, neglogpacs, weights, idx, n, cliprange, adv, log_ratio, st, mom=None):
+        """The launches of one optimiser step up to the gradient.  ``mom`` None: single GPU, the minibatch's own advantage moments.
+        ``mom`` = device [3] float64 holding the GLOBAL moments of this minibatch (``prepare_epoch``): multi-GPU form -- normalise with
+        them, scale by the global count, then ONE all-reduce of [flat grad | loss sums | count]."""
         L = ppo_capi.lib()
         D, A = self.spec.ob_dim, self.spec.ac_dim
         ip = idx.data_ptr()
-        ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), st))
-        ppo_capi.chk(L.ppo_adv_normalize(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), adv.data_ptr(), st))
+        if mom is None:
+            mom = self.moments
+            ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, mom.data_ptr(), st))
+            count = float(n)
+        else:
+            count = float(n) * self._t.distributed.get_world_size(self.comm)       # equal shards: no host read-back of the reduced count
+        ppo_capi.chk(L.ppo_adv_normalize(returns.data_ptr(), values.data_ptr(), ip, n, mom.data_ptr(), adv.data_ptr(), st))
         self.stats.zero_()
         ppo_capi.chk(L.ppo_grad(self.params.data_ptr(), obs.data_ptr(), obs.stride(0), D, A, actions.data_ptr(), adv.data_ptr(),
-                                returns.data_ptr(), neglogpacs.data_ptr(), weights.data_ptr(), ip, n, 1.0 / float(n),
+                                returns.data_ptr(), neglogpacs.data_ptr(), weights.data_ptr(), ip, n, 1.0 / count,
                                 float(cliprange), self.ent_coef, self.vf_coef, self.grads.data_ptr(), self.stats.data_ptr(),
                                 log_ratio.data_ptr(), self.workspace.data_ptr(), st))
+        if self.comm is not None:
+            self._allreduce_grad_and_stats()
+
+    def _allreduce_grad_and_stats(self):
+        """ONE fused collective per optimiser step: [flat grad | 8 loss sums] (the reference's only gradient collective,
+        mpi_adam_optimizer.py:39, all-reduces the flat gradient alone)."""
+        t = self._t
+        self.grads[self.P:self.P + ppo_capi.NSTATS] = self.stats.to(t.float32)
+        sdist.allreduce_fused(self.grads, self.comm)
+        self.stats.copy_(self.grads[self.P:self.P + ppo_capi.NSTATS].to(t.float64))
+
+    def prepare_epoch(self, inds, nbatch_train, returns=None, values=None):
+        """Multi-GPU with equal shards: the advantage moments of ALL minibatches of the coming epoch -- rows
+        ``inds[k * nbatch_train : (k + 1) * nbatch_train]`` of the ``begin_update`` batch (or of ``returns`` / ``values``) -- are summed
+        locally (one small launch per minibatch, no host sync) and all-reduced ONCE as an [nmb, 3] float64 buffer, so that every optimiser
+        step of the epoch issues exactly one collective.  Every rank passes the shuffle of ITS shard (the shuffles need not agree: the
+        global moments of step k are the sum over the ranks of their k-th local minibatch); all ranks must run the same number of
+        minibatches in lockstep.  Without a communicator, or with unequal shards (opponent-data reuse), this is a no-op and the steps all-reduce
+        their own moments as before.  Steps pick their row with ``train_indexed(..., mb_index=k)``."""
+        self._epoch_moments = None
+        if self.comm is None or not self.equal_counts:
+            return None
+        t = self._t
+        if returns is None:
+            if self._static is None or not self._static["open"]:
+                raise ValueError("prepare_epoch needs begin_update() or explicit returns / values")
+            returns, values = self._static["bufs"][1], self._static["bufs"][3]
+        nmb = -(-int(inds.numel()) // int(nbatch_train))
+        mom = t.zeros((nmb, 3), dtype=t.float64, device=self.device)
+        st = t.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+        L = ppo_capi.lib()
+        for k in range(nmb):
+            mb = inds[k * nbatch_train:(k + 1) * nbatch_train]
+            ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), mb.data_ptr(), int(mb.numel()), mom[k].data_ptr(), st))
+        sdist.allreduce_moments(mom, self.comm)
+        self._epoch_moments = mom
+        return mom
 
     def begin_update(self, obs, returns, actions, values, neglogpacs, weights):
         """Hand the batch arrays of ONE update to the model: they are copied (six device copies per update, not per step) into
@@ -128,46 +174,61 @@ class PPOModel(object):
         for dst, x in zip(self._static["bufs"], arrs):
             dst.copy_(x)
         self._static["open"] = True
+        self._epoch_moments = None
 
     def end_update(self):
         if self._static is not None:
             self._static["open"] = False
+        self._epoch_moments = None
 
-    def _graph_step(self, lr, cliprange, idx, n):
+    def _graph_step(self, lr, cliprange, idx, n, mom=None):
+        """``mom`` (multi-GPU: the minibatch's global advantage moments from ``prepare_epoch``): the captured step then holds
+        adv_normalize -> ppo_grad -> fused all-reduce (RCCL calls capture on the stream) -> loss statistics, and the moments are copied
+        into the graph's own buffer before every replay, like the index vector."""
         t = self._t
         A = self.spec.ac_dim
         obs, returns, actions, values, neglogpacs, weights = self._static["bufs"]
-        key = (int(n), float(cliprange))
+        key = (int(n), float(cliprange), mom is not None)
         g = self._graphs.get(key)
         if g is None:
             if len(self._graphs) >= 2:
                 hostcfg.drop_graphs(self._graphs)
             try:
                 ent = dict(idx=t.zeros(n, dtype=t.int32, device=self.device), adv=t.empty(n, dtype=t.float32, device=self.device),
-                           log_ratio=t.empty(n, dtype=t.float32, device=self.device), keep=(obs, returns, actions, values, neglogpacs, weights))
+                           log_ratio=t.empty(n, dtype=t.float32, device=self.device), keep=(obs, returns, actions, values, neglogpacs, weights),
+                           mom=None if mom is None else t.zeros(3, dtype=t.float64, device=self.device))
                 side = t.cuda.Stream(device=self.device)
                 side.wait_stream(t.cuda.current_stream(self.device))
-                with t.cuda.stream(side):       # warm-up outside the capture (one-time kernel attributes, allocator)
+                with t.cuda.stream(side):       # warm-up outside the capture (one-time kernel attributes, allocator, communicator set-up)
                     ent["idx"].copy_(idx)
+                    if mom is not None:
+                        ent["mom"].copy_(mom)
                     self._launch_loss_grad(obs, returns, actions, values, neglogpacs, weights, ent["idx"], n, cliprange, ent["adv"],
-                                           ent["log_ratio"], side.cuda_stream)
+                                           ent["log_ratio"], side.cuda_stream, mom=ent["mom"])
                 t.cuda.current_stream(self.device).wait_stream(side)
                 t.cuda.synchronize(self.device)
                 graph = t.cuda.CUDAGraph()
-                with hostcfg.gc_paused(), t.cuda.graph(graph):
+                # with a collective inside, only this thread's calls belong to the capture (the process group's watchdog thread polls events)
+                gkw = dict(capture_error_mode="thread_local") if mom is not None else {}
+                with hostcfg.gc_paused(), t.cuda.graph(graph, **gkw):
                     cst = t.cuda.current_stream(self.device).cuda_stream
                     self._launch_loss_grad(obs, returns, actions, values, neglogpacs, weights, ent["idx"], n, cliprange, ent["adv"],
-                                           ent["log_ratio"], cst)
+                                           ent["log_ratio"], cst, mom=ent["mom"])
                     ent["out"] = self._loss_stats(cst)
                 ent["graph"] = graph
                 g = self._graphs[key] = ent
             except Exception as e:                     # capture unsupported here: stay on the eager path for good
-                type(self).use_graph = False
+                if mom is not None:
+                    type(self).use_comm_graph = False
+                else:
+                    type(self).use_graph = False
                 hostcfg.drop_graphs(self._graphs)
                 import warnings
                 warnings.warn("HIP graph capture of the PPO step failed (%r); using eager launches" % (e,))
                 return None
         g["idx"].copy_(idx)
+        if mom is not None:
+            g["mom"].copy_(mom)
         g["graph"].replay()
         self.t += 1
         ppo_capi.chk(ppo_capi.lib().ppo_clip_adam(self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
@@ -176,7 +237,16 @@ class PPOModel(object):
                                                    self.stats.data_ptr(), t.cuda.current_stream(self.device).cuda_stream))
         return g["out"].clone()
 
-    def train_indexed(self, lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n, sync=True):
+    # multi-GPU step graph (needs RCCL: gloo's collectives run on the host and cannot be captured)
+    use_comm_graph = os.environ.get("SUMO_PPO_COMM_GRAPH", "1") != "0"
+
+    def _comm_backend(self):
+        try:
+            return self._t.distributed.get_backend(self.comm)
+        except Exception:
+            return None
+
+    def train_indexed(self, lr, cliprange, obs, returns, actions, values, neglogpacs, weights, idx, n, sync=True, mb_index=None):
         """One optimiser step on rows ``idx`` (int32 CUDA tensor or None) of device-resident batch arrays.
         ``sync=False`` skips the host read-back of the loss statistics (returns a device tensor
         [pg, vf, entropy, approxkl, clipfrac] instead) so consecutive minibatch steps queue without host stalls."""
@@ -187,10 +257,17 @@ class PPOModel(object):
         D, A = self.spec.ob_dim, self.spec.ac_dim
         if obs.stride(1) != 1:
             raise ValueError("obs rows must have unit inner stride")
-        if not sync and self.comm is None and idx is not None and self.use_graph and self._static is not None and self._static["open"]:
-            out = self._graph_step(lr, cliprange, idx, n)      # rows come from the begin_update() copies
-            if out is not None:
-                return out
+        em = self._epoch_moments if (self.comm is not None and self.equal_counts and mb_index is not None) else None
+        mom_k = em[int(mb_index)] if em is not None else None                # this minibatch's global moments (prepare_epoch)
+        if not sync and idx is not None and n > 0 and self._static is not None and self._static["open"]:
+            if self.comm is None and self.use_graph:
+                out = self._graph_step(lr, cliprange, idx, n)      # rows come from the begin_update() copies
+                if out is not None:
+                    return out
+            elif mom_k is not None and self.use_graph and self.use_comm_graph and self._comm_backend() == "nccl":
+                out = self._graph_step(lr, cliprange, idx, n, mom=mom_k)
+                if out is not None:
+                    return out
         st = t.cuda.current_stream(self.device).cuda_stream
         ip = ppo_capi.ptr(idx)
         if n == 0:
@@ -205,8 +282,11 @@ class PPOModel(object):
             self.stats.copy_(self.grads[self.P:self.P + ppo_capi.NSTATS].to(t.float64))
             return self._finish_step(lr, sync, t.empty(0, dtype=t.float32, device=self.device), st)
         # advantages: returns - values, normalised over the (global) minibatch (model.py:180-185)
-        ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), st))
-        sdist.allreduce_moments(self.moments, self.comm)
+        if mom_k is not None:          # the epoch's moments were all-reduced in one collective (prepare_epoch): nothing to exchange here
+            self.moments.copy_(mom_k)
+        else:
+            ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), st))
+            sdist.allreduce_moments(self.moments, self.comm)
         adv = t.empty(n, dtype=t.float32, device=self.device)
         ppo_capi.chk(L.ppo_adv_normalize(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), adv.data_ptr(), st))
         if self.comm is None:
@@ -222,10 +302,7 @@ class PPOModel(object):
                                 float(cliprange), self.ent_coef, self.vf_coef, self.grads.data_ptr(), self.stats.data_ptr(),
                                 log_ratio.data_ptr(), self.workspace.data_ptr(), st))
         if self.comm is not None:
-            # ONE fused collective per optimiser step: [flat grad | 5 loss sums | count]
-            self.grads[self.P:self.P + ppo_capi.NSTATS] = self.stats.to(t.float32)
-            sdist.allreduce_fused(self.grads, self.comm)
-            self.stats.copy_(self.grads[self.P:self.P + ppo_capi.NSTATS].to(t.float64))
+            self._allreduce_grad_and_stats()
         return self._finish_step(lr, sync, log_ratio, st)
 
     def _loss_stats(self, st):

@@ -328,6 +328,29 @@ def test_config5_shard_pool_rollout_and_bptt_update_vs_oracle(tmp_path):
     assert len(model.history["opponent_versions"]) == 3 and len(model.history["opponent_versions"][2]) == 16
     assert all(np.isfinite(l).all() for l in model.history["lossvals"]) and torch.isfinite(model.params).all()
     env.close()
+    # the 'ours' selector (ratio-divergence sampling, alg_ppo.py:227-244) with a recurrent pool: its reference opponent is the
+    # single-snapshot model, which holds checkpoint 00000 at update 2 (alg_ppo.py:208), not its own random initialisation
+    env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=64, seed=52)
+    seen = {}
+    orig_sel = alg_ppo.selection_probs
+
+    def spy(ap, naps):
+        cv = lambda x: x.detach().cpu().numpy().copy() if torch.is_tensor(x) else np.asarray(x).copy()
+        seen.setdefault("calls", []).append((cv(ap), [cv(x) for x in naps]))
+        return orig_sel(ap, naps)
+    alg_ppo.selection_probs = spy
+    try:
+        model = alg_ppo.learn(network="lstm", env=env, seed=5, total_timesteps=64 * 8 * 3, nagent=2, log_dir=str(tmp_path / "ours"), verbose=False,
+                              nsteps=8, nminibatches=4, noptepochs=1, lr=3e-4, gamma=0.995, lam=1.0, rho_bar=10.0, c_bar=1.0, opponent_mode="ours",
+                              nlstm=128, anneal_bound=1000, opponent_pool=4)
+    finally:
+        alg_ppo.selection_probs = orig_sel
+    assert len(seen["calls"]) == 2                                   # updates 2 and 3
+    ap, naps = seen["calls"][0]
+    # at update 2 the candidates are checkpoints 00000 and 00001; the reference opponent IS 00000: its likelihoods equal candidate 0's
+    assert len(naps) == 2 and np.allclose(ap, naps[0], rtol=1e-5, atol=1e-5) and not np.allclose(ap, naps[1], rtol=1e-3, atol=1e-3)
+    assert all(np.isfinite(l).all() for l in model.history["lossvals"])
+    env.close()
 
 
 @pytest.mark.parametrize("T,n,D,A,H", [(5, 33, 121, 8, 128), (9, 40, 209, 16, 64), (3, 7, 13, 3, 64)])

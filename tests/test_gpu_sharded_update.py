@@ -178,6 +178,144 @@ def test_rccl_process_group_world_size_one():
     assert np.allclose(p, ref_p, rtol=0, atol=2e-6) and np.allclose(st, ref_st, rtol=1e-4, atol=1e-6)
 
 
+# ---- the epoch's advantage moments in ONE all-reduce, then exactly one collective per optimiser step ------------
+def _train_epochs(comm, lo, hi, nmb=4, epochs=2, count_calls=None):
+    """begin_update -> per epoch: shuffle, prepare_epoch, nmb asynchronous steps (the loop of alg_ppo.learn / bench.py)."""
+    import torch
+    from robosumo_selfplay_amd import dist as sdist, model as model_mod, policies
+    np.random.seed(3)
+    spec = policies.PolicySpec(OB, AC, value_network="copy", activation="relu")
+    m = model_mod.PPOModel(policy=spec, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, comm=comm)
+    sdist.broadcast_params(m.params, comm)
+    obs, act, ret, val, old = (torch.as_tensor(x[lo:hi]).cuda() for x in _batch())
+    n = hi - lo
+    w = torch.ones(n, dtype=torch.float32, device="cuda")
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)                                   # the SAME local permutation on every rank: rank r's k-th minibatch is then the
+    m.begin_update(obs, ret, act, val, old, w)           # r-th part of the single process's k-th minibatch (see _ref_epochs)
+    outs = []
+    for ep in range(epochs):
+        inds = torch.randperm(n, device="cuda", generator=gen).to(torch.int32)
+        m.prepare_epoch(inds, n // nmb)
+        for k in range(nmb):
+            mb = inds[k * (n // nmb):(k + 1) * (n // nmb)]
+            outs.append(m.train_indexed(1e-3, 0.2, obs, ret, act, val, old, w, mb, int(mb.numel()), sync=False, mb_index=k))
+    m.end_update()
+    torch.cuda.synchronize()
+    sdist.assert_synced(m.params, comm)
+    return m.params.cpu().numpy(), torch.stack(outs).cpu().numpy(), sorted(k for k in m._graphs)
+
+
+def _ref_epochs(world, nmb=4, epochs=2):
+    """Single process on the whole batch with the minibatches the `world` ranks form together: rank r holds rows [r per, (r+1) per) and
+    every rank draws the same local permutation, so global minibatch k = union over r of (r per + local k-th slice)."""
+    import torch
+    from robosumo_selfplay_amd import model as model_mod, policies
+    np.random.seed(3)
+    spec = policies.PolicySpec(OB, AC, value_network="copy", activation="relu")
+    m = model_mod.PPOModel(policy=spec, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5)
+    obs, act, ret, val, old = (torch.as_tensor(x).cuda() for x in _batch())
+    w = torch.ones(N, dtype=torch.float32, device="cuda")
+    per = N // world
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    m.begin_update(obs, ret, act, val, old, w)
+    for ep in range(epochs):
+        inds = torch.randperm(per, device="cuda", generator=gen).to(torch.int32)
+        for k in range(nmb):
+            loc = inds[k * (per // nmb):(k + 1) * (per // nmb)]
+            mb = torch.cat([loc + r * per for r in range(world)]).contiguous()
+            m.train_indexed(1e-3, 0.2, obs, ret, act, val, old, w, mb, int(mb.numel()), sync=False)
+    m.end_update()
+    torch.cuda.synchronize()
+    return m.params.cpu().numpy()
+
+
+def _epoch_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"n": 0}
+    orig = dist.all_reduce
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    dist.all_reduce = counted
+    per = N // world
+    p, st, _ = _train_epochs(dist.group.WORLD, rank * per, (rank + 1) * per)
+    dist.all_reduce = orig
+    q.put((rank, p, st, calls["n"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_one_collective_per_step_with_epoch_moments():
+    """2 ranks: per epoch ONE all-reduce of the [nmb, 3] advantage moments, then one fused all-reduce per optimiser step (was two per
+    step); parameters equal a single-process run on the minibatches the two ranks form together (2e-5, as test_microbatches.py does
+    for its full-batch / micro-batch pair at 3e-3)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_epoch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, p, st, ncalls = q.get(timeout=300)
+        res[r] = (p, st, ncalls)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    nmb, epochs = 4, 2
+    # per epoch: 1 (moments) + nmb (fused gradient) all-reduces; + the two of assert_synced
+    assert res[0][2] == res[1][2] == epochs * (1 + nmb) + 2, res[0][2]
+    assert np.array_equal(res[0][0], res[1][0])
+    ref = _ref_epochs(2)
+    assert np.allclose(res[0][0], ref, rtol=0, atol=2e-5), np.abs(res[0][0] - ref).max()
+    assert np.isfinite(res[0][1]).all() and np.allclose(res[0][1], res[1][1])          # loss statistics are global: same on both ranks
+
+
+def _rccl_graph_worker(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    p, st, keys = _train_epochs(dist.group.WORLD, 0, N)
+    q.put((p, st, keys))
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not has_gpu(), reason="needs a GPU")
+def test_rccl_step_graph_holds_the_collective():
+    """RCCL ('nccl', one rank -- a second rank needs a second GPU): the multi-GPU optimiser step -- adv_normalize, ppo_grad, the fused
+    all-reduce, loss statistics -- is captured into ONE HIP graph with the collective inside and replayed per minibatch; same update as
+    the single-GPU graph."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_graph_worker, args=(port, q))
+    pr.start()
+    p, st, keys = q.get(timeout=300)
+    pr.join(timeout=120)
+    assert pr.exitcode == 0
+    assert keys and all(k[2] for k in keys), keys                    # the comm variant of the step graph was captured (no eager fallback)
+    ref = _ref_epochs(1)
+    assert np.allclose(p, ref, rtol=0, atol=2e-6), np.abs(p - ref).max()
+    assert np.isfinite(st).all()
+
+
 # ---- the same for the recurrent model: each rank back-propagates through its own env sequences -----------------------
 LT, LN, LD, LA, LH = 6, 16, 17, 3, 64
 

@@ -20,7 +20,7 @@ for W in "$@"; do
   esac
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- $P > $O/stats.log 2>&1 || exit 11
   cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_${W}_kernel_stats.csv
-  tail -1 $O/stats.log > $O/${TAG}_${W}_workload.json
+  grep "^{" $O/stats.log | tail -1 > $O/${TAG}_${W}_workload.json
   echo "$W stats done"
   if [ "$W" = "mfma" ]; then
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/mf -o $TAG -- $P > $O/mf.log 2>&1 || exit 12
