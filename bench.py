@@ -516,8 +516,8 @@ def main():
             try:
                 from oracle import subproc_baseline
                 v3 = subproc_baseline.run(args.env_id, 8, 1500, model.act_dims[0])
-                out["cpu_baseline"]["subproc8"] = {"value": v3, "cores": 8, "sample": "8 single-env worker processes x 1500 lock-step steps over pipes "
-                                                   "(from the reset law, N(0,1) actions)"}
+                out["cpu_baseline"]["subproc8"] = {"value": v3, "cores": 8, "sample": "8 single-env worker processes x 1500 lock-step steps over pipes, the five policy / "
+                                                   "value passes of every step evaluated in numpy on the parent (random-init MLP(64,64) nets, from the reset law)"}
             except Exception as e:                                    # the harness is a report, never a reason to lose the bench line
                 out["cpu_baseline"]["subproc8"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

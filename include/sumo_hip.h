@@ -154,7 +154,7 @@ int sumo_debug_fault(sumo_handle_t h, int env);
 /* device-side statistics accumulated since creation: forward calls, newton iterations, contacts, efc rows,
  * max ncon, max nefc, max newton iterations, dropped contacts, diverged env steps, aborted waits of the fused rollout's step
  * hand-over, hand-over tag / checksum mismatches (both always 0 unless a launch was cut short); contact-generation fidelity
- * accounting: capsule-box calls that yielded 3 active contacts (MuJoCo's mjc_CapsuleBox yields at most 2), active contacts on a
+ * accounting, SAMPLED in the forward evaluation that opens each env step (1 in 20 forwards): capsule-box calls that yielded 3 active contacts (MuJoCo's mjc_CapsuleBox yields at most 2), active contacts on a
  * border rod beyond the cylinder's flat end (the rods collide as capsules of the same radius / half length: the only place where
  * the shape differs from MuJoCo's cylinder) (HOST float64 [SUMO_NSTATS]). */
 #define SUMO_NSTATS 13

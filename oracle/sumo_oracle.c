@@ -513,7 +513,7 @@ static void collision(const so_sim* s, env_t* d) {
       else if (u1 == SUMO_GEOM_CAPSULE && u2 == SUMO_GEOM_BOX) n = capsule_box(tmp, margin, p1, m1, s1, p2, m2, s2);
       else n = 0; /* plane-box etc.: static-static, filtered at compile time */
     }
-    {
+    if ((d->n_forward - 1) % 20 == 0) { /* sampled like the engine: the forward evaluation that opens an env step (1 in 20) */
       int nact = 0;
       for (int i = 0; i < n; i++) nact += tmp[i].dist < margin;
       if (nact == 3) d->n_cb3++;

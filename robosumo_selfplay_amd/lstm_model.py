@@ -7,8 +7,10 @@ recurrent minibatch convention of baselines ppo2 (whole env sequences per miniba
 fork's own copy of that loop, alg_ppo.py:408-421, passes the states as ``IS_weight`` and cannot run -- SURVEY.md App. C.3).
 
 Kernels (include/sumo_ppo.h): ``ppo_lstm_step`` (acting), ``ppo_lstm_step_save`` (unrolled forward that records gates),
-``ppo_lstm_head_grad`` (loss + head gradients on the stored latents), ``ppo_lstm_bwd_step`` (one BPTT step), then the
-weight gradients as plain library GEMMs (``torch.matmul`` = hipBLASLt) and ``ppo_clip_adam``.
+``ppo_lstm_head_grad`` (loss + head gradients on the stored latents), ``ppo_lstm_bwd_step`` (one BPTT step; nlstm = 128: the whole
+sequence in one launch each way, ``ppo_lstm_seq_forward`` / ``ppo_lstm_seq_backward``), the weight gradients by the hand-written
+split-K MFMA kernel ``ppo_lstm_wgrad`` (``SUMO_LSTM_WGRAD=blas`` keeps ``torch.matmul`` = hipBLASLt as a cross-check only) and
+``ppo_clip_adam``.
 """
 import ctypes as C
 import os

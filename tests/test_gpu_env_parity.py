@@ -158,29 +158,34 @@ def test_terminal_and_timeout_on_device():
     assert np.all(gobs[:3, :, 120] == -1.0) and gobs[3, 0, 120] == np.float32(-1 + 2 * 21 / 500)
 
 
-def test_batch_independence_and_determinism():
-    """Size-independent properties at the benchmark size (4096 envs): env e's trajectory does not depend on the batch
-    it is in, repeated runs are bitwise identical, quaternions stay unit, everything stays finite."""
-    m = mjcf.load_model("RoboSumo-Ant-vs-Ant-v0")
+@pytest.mark.parametrize("env_id", ["RoboSumo-Ant-vs-Ant-v0", "RoboSumo-Spider-vs-Spider-v0"])
+def test_batch_independence_and_determinism(env_id):
+    """Size-independent properties at the benchmark size (4096 envs; BASELINE configs 2 and 4): env e's trajectory does not depend
+    on the batch it is in, repeated runs are bitwise identical, quaternions stay unit, everything stays finite."""
+    m = mjcf.load_model(env_id)
     dev = torch.device("cuda:0")
+    A = int(m.act_dims[0])
+    qa = [int(x) for x in m.agent_qposadr]
     outs = []
     for N in (4096, 4096, 96):
-        env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=N, seed=7, model=m)
+        env = SumoVecEnv(env_id, num_envs=N, seed=7, model=m)
         env.reset_device()
         g = torch.Generator(device="cpu").manual_seed(0)
-        acts = torch.randn((6, 4096, 2, 8), generator=g).to(dev)
+        acts = torch.randn((6, 4096, 2, A), generator=g).to(dev)
         for t in range(6):
             obs, info, done, *_ = env.step_device(acts[t, :N].contiguous())
         torch.cuda.synchronize()
         q, v, w, c = env.engine.get_state()
         outs.append((obs.cpu().numpy().copy(), q, v))
+        st = env.stats()
         env.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][0][:96], outs[2][0]) and np.array_equal(outs[0][1][:96], outs[2][1])
     q = outs[0][1]
     assert np.isfinite(outs[0][0]).all() and np.isfinite(q).all() and np.isfinite(outs[0][2]).all()
-    assert np.allclose(np.linalg.norm(q[:, 3:7], axis=1), 1.0, atol=1e-12)
-    assert np.allclose(np.linalg.norm(q[:, 18:22], axis=1), 1.0, atol=1e-12)
+    for a in qa:
+        assert np.allclose(np.linalg.norm(q[:, a + 3:a + 7], axis=1), 1.0, atol=1e-12)
+    assert st["diverged"] == 0
 
 
 def test_vecenv_host_api_matches_reference_contract():

@@ -1,5 +1,6 @@
 """Recurrent PPO training on the GPU (robosumo_selfplay_amd/lstm_model.py) against the finite-difference-verified numpy BPTT in
-oracle/ppo_oracle.py.  Tolerances: float32 MFMA / hipBLASLt GEMMs vs float64 numpy -> 3e-4 of each tensor's gradient scale."""
+oracle/ppo_oracle.py.  Tolerances: float32 MFMA kernels (forward, BPTT, the split-K weight-gradient kernel ppo_lstm_wgrad) vs float64
+numpy -> 3e-4 of each tensor's gradient scale."""
 import os
 
 import numpy as np
@@ -266,7 +267,7 @@ def test_config5_shard_pool_rollout_and_bptt_update_vs_oracle(tmp_path):
     """BASELINE config 5 on its one-GPU shard: Ant-vs-Ant, 1024 envs, LSTM(128) learner, a pool of 16 frozen LSTM snapshots (one per
     16-env tile), rollout in the device-mode recurrent Runner, then ONE whole-sequence minibatch update (128 env sequences x 32
     steps) checked against the numpy BPTT + TF1-Adam restatement (oracle/ppo_oracle.py, finite-difference verified).
-    Tolerances: loss terms 1e-3 relative, parameters after the step 3e-5 absolute (float32 MFMA / hipBLASLt vs float64)."""
+    Tolerances: loss terms 1e-3 relative, parameters after the step 3e-5 absolute (float32 MFMA kernels vs float64)."""
     from robosumo_selfplay_amd import alg_ppo
     from robosumo_selfplay_amd.opponent_pool import LstmOpponentPool
     from robosumo_selfplay_amd.runner import Runner

@@ -53,22 +53,21 @@ def test_adjust_z_step_parity(env_id, tol):
     for t in range(30):
         a = (rng.standard_normal((p.N, 2, p.eng.act_stride)) * 2.0).astype(np.float32)
         lay = t == 10 and env_id == "RoboSumo-Ant-vs-Ant-v0"
-        if lay:         # lay agent 0 of a few envs on the mat, legs folded up: z - 0.5 < 0.29 -> lost (would not be with adjust_z = 0)
+        if lay:         # agent 0 of a few envs on its back, torso just above the mat (legs in the air): z - 0.5 < 0.29 -> lost (not with adjust_z = 0)
             q, v, w, c = p.ora.get_state()
-            q[:8, 2] = 0.76
-            q[:8, 3:7] = [1.0, 0.0, 0.0, 0.0]                     # upright, so that the folded legs do not reach the mat
-            q[:8, 7:15] = [0.0, 1.0, 0.0, -1.0, 0.0, -1.0, 0.0, 1.0]
+            q[:8, 2] = 0.765
+            q[:8, 3:7] = [0.0, 1.0, 0.0, 0.0]                     # half a turn about x
             v[:8] = 0.0
             w[:8] = 0.0
             a[:8] = 0.0
             p.ora.set_state(q, v, w, c); p.eng.set_state(q, v, w, c)
         (gobs, ginfo, gdone, gr, gdr, gl), (oobs, oinfo, odone, orr, odr, ol) = p.step(a)
         assert np.array_equal(gdone, odone) and np.array_equal(gl, ol)
-        if tol <= 1e-9:
+        if tol <= 1e-9 and not lay:
             assert np.array_equal(gobs, oobs)
-        else:
+        else:       # (the laid-down pose has exactly parallel / axis-aligned capsules: the narrow phase's degenerate branches differ in the last bits)
             assert np.abs(gobs - oobs).max() < 1e-5
-        assert relerr(ginfo, oinfo) < tol
+        assert relerr(ginfo, oinfo) < (max(tol, 1e-7) if lay else tol)
         if lay:
             assert gdone[:8, 0].all() and (ginfo[:8, 0, 1] == -2000).all()
         ndone += int(gdone[:, 0].sum())
@@ -113,7 +112,7 @@ def test_zoo_selfplay_matches_mujoco_filter_statistics(kind, net):
         assert r["episodes"] >= 256 and r["decided"] >= 0.8, (cfrc_mode, r["episodes"], r["decided"])
         assert r["stats"]["diverged"] == 0
         for b in KIN_BLOCKS:
-            assert rep[b]["max_dev"] <= 0.5, (cfrc_mode, b, rep[b])
+            assert rep[b]["max_dev"] <= KIN_TOL[cfrc_mode], (cfrc_mode, b, rep[b])
         if cfrc_mode == "rne_post":
             lo, hi = FORCE_BAND[kind]
             assert lo <= rep["force_ratio"] <= hi and lo <= rep["torque_ratio"] <= hi + 0.1, rep
