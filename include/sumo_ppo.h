@@ -182,7 +182,8 @@ int ppo_adv_normalize(const float* returns, const float* values, const int32_t* 
  * sum-loss = sum_i w_i*pg_i + vf_coef * sum_i 0.5 (v_i-R_i)^2 - n_local*ent_coef*entropy, where every per-row term
  * is pre-divided by inv_count = 1/global_count (so summing grads over ranks gives the gradient of the global mean loss).
  * stats double[PPO_NSTATS] accumulate the un-normalised sums.  log_ratio_out [n] (minibatch order) may be NULL.
- * workspace: ppo_grad_workspace_bytes(ob_dim, ac_dim) bytes of scratch. */
+ * workspace: ppo_grad_workspace_bytes(ob_dim, ac_dim) bytes of scratch, ZERO-INITIALISED once by the caller (its tail holds the arrival
+ * counters of the in-launch slab reduction, which every call leaves at zero); one ppo_grad in flight per workspace. */
 size_t ppo_grad_workspace_bytes(int ob_dim, int ac_dim);
 int ppo_grad(const float* params, const float* obs, int obs_stride, int ob_dim, int ac_dim, const float* actions,
              const float* adv_mb, const float* returns, const float* old_neglogp, const float* is_weight,

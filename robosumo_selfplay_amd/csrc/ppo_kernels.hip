@@ -1586,35 +1586,45 @@ __global__ void __launch_bounds__(256, (KT <= 8 ? 2 : 1)) ppo_grad_kernel(GradAr
   else grad_net_coop<KT, false>(a, smem_f, lane, wid);
 }
 
-// grads[p] = sum over waves of the slab of the net that owns p; stats += per-wave stats.  Two passes so that the 100 MB of
-// slabs (one per wave) are streamed by thousands of workgroups instead of P threads: groups of RED_GROUP consecutive slabs
-// are summed in order into partial[g][p], then the partials in order -- a fixed association, hence deterministic.
+// grads[p] = sum over workgroups of the slab of the net that owns p; stats += per-workgroup stats.  ONE launch, two levels, fixed
+// association (deterministic, no float atomics): workgroup (chunk, g) sums the RED_GROUP consecutive slabs of group g for its 256
+// parameters into partial[g][p]; the LAST workgroup of a chunk to finish (a counter per chunk; the partials travel through sc1
+// stores / loads, so the other XCDs' L2s do not matter) adds the G partials in order and writes grads.  The last workgroup of chunk 0
+// also sums the statistics records.  The counters live in the caller's workspace, start at zero and are left at zero.
 #define RED_GROUP 16
-__global__ void __launch_bounds__(256) ppo_grad_reduce1_kernel(const float* slabs, int nwaves, ParamLayout L, float* partial) {
+__global__ void __launch_bounds__(256) ppo_grad_reduce_kernel(const float* slabs, int nslabs, ParamLayout L, float* partial, int G,
+                                                              unsigned int* arrived, const double* wstats, float* grads, double* stats) {
   const int p = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-  if (p >= L.P) return;
-  const bool is_vf = (p >= L.vf_w0 && p < L.pi_w) || p >= L.vf_w;
-  const float* s = slabs + (size_t)(is_vf ? 1 : 0) * nwaves * L.P + p;
-  const int w0 = g * RED_GROUP, w1 = w0 + RED_GROUP < nwaves ? w0 + RED_GROUP : nwaves;
-  float v[RED_GROUP];
+  __shared__ int last;
+  if (p < L.P) {
+    const bool is_vf = (p >= L.vf_w0 && p < L.pi_w) || p >= L.vf_w;
+    const float* s = slabs + (size_t)(is_vf ? 1 : 0) * nslabs * L.P + p;
+    const int w0 = g * RED_GROUP, w1 = w0 + RED_GROUP < nslabs ? w0 + RED_GROUP : nslabs;
+    float v[RED_GROUP];
 #pragma unroll
-  for (int k = 0; k < RED_GROUP; k++) v[k] = w0 + k < w1 ? s[(size_t)(w0 + k) * L.P] : 0.0f;   // all loads in flight
-  float acc = 0.0f;
+    for (int k = 0; k < RED_GROUP; k++) v[k] = w0 + k < w1 ? s[(size_t)(w0 + k) * L.P] : 0.0f;   // all loads in flight
+    float acc = 0.0f;
 #pragma unroll
-  for (int k = 0; k < RED_GROUP; k++) acc += v[k];
-  partial[(size_t)g * L.P + p] = acc;
-}
-__global__ void __launch_bounds__(256) ppo_grad_reduce2_kernel(const float* partial, int G, const double* wstats, int nwaves, ParamLayout L,
-                                                               float* grads, double* stats) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+    for (int k = 0; k < RED_GROUP; k++) acc += v[k];
+    __hip_atomic_store(partial + (size_t)g * L.P + p, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                       // every thread's partial has left for memory
+  if (threadIdx.x == 0) {
+    const unsigned int n = __hip_atomic_fetch_add(arrived + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (n == (unsigned int)G - 1);
+    if (last) __hip_atomic_store(arrived + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+  }
+  __syncthreads();
+  if (!last) return;
   if (p < L.P) {
     float acc = 0.0f;
-    for (int g = 0; g < G; g++) acc += partial[(size_t)g * L.P + p];
+    for (int q = 0; q < G; q++) acc += __hip_atomic_load(partial + (size_t)q * L.P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     grads[p] = acc;
   }
-  if (blockIdx.x == 0) {   // 8 statistics x 2*nwaves entries: 32 chunks per statistic in parallel, then the chunks in order
-    __shared__ double chunk[32][8];
-    const int k = threadIdx.x & 7, c = threadIdx.x >> 3, n = 2 * nwaves, per = (n + 31) / 32;
+  if (blockIdx.x == 0) {   // 8 statistics x 2*nslabs records (written by the gradient kernel, i.e. before this launch): 32 chunks per
+    __shared__ double chunk[32][8];                                         // statistic in parallel, then the chunks in order
+    const int k = threadIdx.x & 7, c = threadIdx.x >> 3, n = 2 * nslabs, per = (n + 31) / 32;
     double acc = 0;
     for (int w = c * per; w < (c + 1) * per && w < n; w++) acc += wstats[(size_t)w * 8 + k];
     chunk[c][k] = acc;
@@ -1631,7 +1641,8 @@ static int grad_nwaves(void) { return 256 * 4; }   // slabs per net the workspac
 extern "C" size_t ppo_grad_workspace_bytes(int ob_dim, int ac_dim) {
   ParamLayout L = make_layout(ob_dim, ac_dim);
   return (size_t)2 * grad_nwaves() * L.P * sizeof(float) + (size_t)2 * grad_nwaves() * 8 * sizeof(double) +
-         (size_t)(grad_nwaves() / RED_GROUP) * L.P * sizeof(float);   // slabs | per-wave stats | partial sums
+         (size_t)(grad_nwaves() / RED_GROUP) * L.P * sizeof(float) +      // slabs | per-workgroup stats | partial sums
+         (size_t)((L.P + 255) / 256) * sizeof(unsigned int);              // | arrival counter per 256-parameter chunk (zero between calls)
 }
 
 extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, int ob_dim, int ac_dim, const float* actions,
@@ -1681,8 +1692,9 @@ extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, i
   {
     float* partial = (float*)((char*)workspace + (size_t)2 * grad_nwaves() * a.L.P * sizeof(float) + (size_t)2 * grad_nwaves() * 8 * sizeof(double));
     const int G = (a.nwaves + RED_GROUP - 1) / RED_GROUP;
-    hipLaunchKernelGGL(ppo_grad_reduce1_kernel, dim3((a.L.P + 255) / 256, G), dim3(256), 0, s, a.slabs, a.nwaves, a.L, partial);
-    hipLaunchKernelGGL(ppo_grad_reduce2_kernel, dim3((a.L.P + 255) / 256), dim3(256), 0, s, partial, G, a.wstats, a.nwaves, a.L, grads, stats);
+    unsigned int* arrived = (unsigned int*)(partial + (size_t)(grad_nwaves() / RED_GROUP) * a.L.P);
+    hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3((a.L.P + 255) / 256, G), dim3(256), 0, s, a.slabs, a.nwaves, a.L, partial, G, arrived,
+                       a.wstats, grads, stats);
   }
   HIPCHK(hipGetLastError());
   return 0;

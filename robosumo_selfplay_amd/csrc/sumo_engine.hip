@@ -468,6 +468,9 @@ struct Ctx {
   // as capsules: only there does the shape differ from MuJoCo's cylinder)
   int st_cb3, st_rodcap;
   int hcross;
+#ifdef SUMO_DBG_DUMP
+  double* dbg;   // development: intermediate vectors of env 0's first two forward evaluations (sumo_debug_dump)
+#endif
 };
 
 #define S(off) (c.sm + c.L.off)
@@ -1774,15 +1777,24 @@ __device__ __forceinline__ void newton_solve(C& c) {
   SYNC();
 }
 
+#ifdef SUMO_DBG_DUMP
+#define DUMP(slot, ptr, n) do { if (c.dbg && c.st_forward <= 20 && c.lane < (n)) c.dbg[((c.st_forward - 1) * 8 + (slot)) * 64 + c.lane] = (ptr)[c.lane]; } while (0)
+#else
+#define DUMP(slot, ptr, n) do { } while (0)
+#endif
 // ---- mj_forward ----------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void forward(C& c) {
   const sumo_model_t& mdl = c.P->mdl;
   const int lane = c.lane, nv = mdl.nv;
   c.st_forward++;
+  DUMP(0, S(qpos), mdl.nq); DUMP(1, S(qvel), nv); DUMP(2, S(ctrl), mdl.nu); DUMP(7, S(warm), nv);
   position_velocity(c);
   collision(c);
   make_constraint(c);
+#ifdef SUMO_DBG_DUMP
+  if (c.dbg && c.st_forward <= 20 && lane < 3) c.dbg[((c.st_forward - 1) * 8 + 5) * 64 + lane] = lane == 0 ? c.ncon : (lane == 1 ? c.nefc : c.nlim);
+#endif
   // efc_vel and aref (B and K*imp*(pos-margin) were parked in Jv / jar)
   contact_Jx(c, S(qvel));
   for (int r = lane; r < 4 * c.ncon; r += WAVE) S(aref)[r] = -S(aref)[r] * row_Jx(c, r) - S(jar)[r];  // B was parked in aref
@@ -1801,6 +1813,7 @@ __device__ __forceinline__ void forward(C& c) {
     S(qsm)[K.a_dof] += K.a_gear * u;  // one motor per dof in these scenes
   }
   SYNC();
+  DUMP(3, S(qsm), nv);
   // qacc_smooth = M^-1 qfrc_smooth
   int mfail;
   double as;
@@ -1822,6 +1835,7 @@ __device__ __forceinline__ void forward(C& c) {
   if (lane < nv) S(asmo)[lane] = as;
   SYNC();
   PROF(10);
+  DUMP(4, S(asmo), nv);
   if (c.htree) newton_solve<true>(c);
   else {
     // The general (dense-factorisation) path costs ~1.65x a tree-path forward and the envs on it -- agents in contact with each
@@ -1833,6 +1847,7 @@ __device__ __forceinline__ void forward(C& c) {
     if (c.hcross) c.st_cross++;
   }
   PROF(16);
+  DUMP(6, S(x), nv);
   c.st_ncon += c.ncon;
   c.st_nefc += c.nefc;
   if (c.ncon > c.st_maxcon) c.st_maxcon = c.ncon;
@@ -2162,6 +2177,21 @@ __device__ __forceinline__ void sched_rank(const int* __restrict__ cost, int n, 
 }
 
 extern __shared__ double smem_dyn[];
+#ifdef SUMO_DBG_POISON_LDS
+// development: every LDS word holds a signalling pattern before an env step starts, so that a phase that reads a word nobody
+// wrote shows up as NaN in the parity tests instead of depending on what the previous step / workgroup left there
+__device__ __forceinline__ void poison_lds(const Params* P, int lane) {
+  const int n = P->L.total_bytes / 8;
+  for (int i = lane; i < n; i += WAVE) smem_dyn[i] = (SUMO_DBG_POISON_LDS == 2 ? __longlong_as_double(0x7FF8DEADBEEF0000ll) : (SUMO_DBG_POISON_LDS == 1 ? 1e300 : 0.0));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {   // what ctx_init keeps in LDS for the whole launch: the world geoms' centres / axes
+    const int nb = P->mdl.nbody, nw = P->aux.nworld;
+    const double* wpos = P->aux.af + P->aux.o_wpa;
+    for (int i = lane; i < 3 * nw; i += WAVE) { smem_dyn[P->L.xipos + 3 * nb + i] = wpos[i]; smem_dyn[P->L.gaxis + 3 * nb + i] = wpos[3 * nw + i]; }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+#endif
 
 // One env step of env `e` by this wave: state record -> LDS, frame_skip x RK4 mj_step, game rules, rewards, done, auto-reset,
 // observation write, state record back (the whole of SumoEnv._step + the wrappers + the worker's auto-reset:
@@ -2185,6 +2215,13 @@ __device__ __forceinline__ void env_step_body(C& c, const SA& a, int e) {
         if (a.stats) atomicAdd(a.stats + 10, 1ull);
       }
     }
+  }
+#endif
+#ifdef SUMO_DBG_RELOAD_CTRL
+  if (COH && lane < mdl.nu) {
+    const float* act0 = a.actions + (size_t)e * 2 * a.act_stride;
+    int ag = lane >= MI(agent_uadr)[1] ? 1 : 0;
+    S(ctrl)[lane] = (double)hand_load<true>(act0 + ag * a.act_stride + (lane - MI(agent_uadr)[ag]));
   }
 #endif
   if (!COH && lane < mdl.nu) {   // fused rollout: the policy phase has put the step's actions into S(ctrl) itself
@@ -2316,6 +2353,12 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   if (bid >= a.N) return;
   const int e = a.perm ? a.perm[bid] : bid;
   if (a.perm && bid < (a.N >> 3)) __builtin_amdgcn_s_setprio(1);   // predicted-longest eighth of the launch: issue ahead of the SIMD mate
+#ifdef SUMO_DBG_POISON_LDS
+  poison_lds(P, lane);
+#endif
+#ifdef SUMO_DBG_DUMP
+  c.dbg = e == 0 ? a.dbg_qacc : nullptr;
+#endif
   env_step_body(c, a, e);
   flush_stats(c, a.stats);
 }
@@ -2707,6 +2750,9 @@ sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
     }
     __builtin_amdgcn_s_setprio(0);   // a wave that raised its issue priority for a dense-solver step (forward()) starts the next ticket level
     // (e, k) wait in LDS during the phases (nothing but the context stays live across the forward-dynamics evaluations)
+#ifdef SUMO_DBG_POISON_LDS
+    poison_lds(P, c.lane);
+#endif
     if (c.lane == 0) { int* tk = (int*)(S(stash) + 4); tk[0] = e; tk[1] = k; }
     lp = launder_sptr(LP);
     int s = lp->r.s0 + k;
@@ -2715,8 +2761,15 @@ sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
     unsigned long long* prof = lp->r.prof;
     unsigned long long t0 = 0;
     if (prof && c.lane == 0) { t0 = wall_clock64(); if (k == 0) atomicExch(prof + PROF_STRIDE * e, t0); }
+#ifdef SUMO_DBG_DUMP
+    c.dbg = (e == 0 && k == 0) ? lp->a.dbg_qacc : nullptr;
+    if (c.dbg) c.st_forward = 0;
+#endif
     if constexpr (POLICY == 1) rollout_policy_phase_lstm<128>(c, lp->a, lp->r, e, s);
     else rollout_policy_phase(c, lp->a, lp->r, e, s);
+#ifdef SUMO_DBG_HARD_BARRIER
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
     prof = launder_sptr(LP)->r.prof;
     if (prof && c.lane == 0) { const unsigned long long t1 = wall_clock64(); atomicAdd(prof + PROF_STRIDE * e + 2, t1 - t0); S(stash)[11] = __longlong_as_double((long long)t1); }
     env_step_body<true>(c, launder_sptr(LP)->a, e);
@@ -2823,6 +2876,7 @@ struct sumo_engine {
   hipStream_t rollout_stream = nullptr;    // stream of the most recent fused launch (sumo_rollout_status waits on it)
   long long rollout_tickets = -1;          // N * K of the most recent fused launch, -1: none yet
   int dbg_fault_env = -1;                  // sumo_debug_fault
+  double* dbg_dump = nullptr;              // sumo_debug_dump (SUMO_DBG_DUMP builds)
   unsigned long long acked_faults = 0;     // stats[9] + stats[10] already reported by sumo_rollout_status
   long long sched_t = 0;                                                                     // step launches so far (in-kernel ranking)
   void* d_sort_tmp = nullptr;
@@ -3402,6 +3456,7 @@ static StepArgs base_args(sumo_engine* E) {
   a.state = E->d_state; a.counters = E->d_counters; a.seeds = E->d_seeds; a.state_stride = E->state_stride;
   a.stats = E->d_stats; a.obs_stride = E->obs_stride; a.act_stride = E->act_stride; a.N = E->N;
   a.dbg_fault_env = -1;
+  a.dbg_qacc = E->dbg_dump;
   return a;
 }
 
@@ -3647,6 +3702,11 @@ extern "C" int sumo_rollout_status(sumo_handle_t E, int64_t* out4) {
                 "since creation; %d of %lld tickets were drawn): the rollout buffers hold unwritten rows and the env states are "
                 "partly advanced -- reset the envs before continuing", st[0], st[1], sc[0], E->rollout_tickets);
   } else if (out4) for (int i = 0; i < 4; i++) out4[i] = o[i];
+  return 0;
+}
+extern "C" int sumo_debug_dump(sumo_handle_t E, double* dev_buf /* [2][8][64] or NULL */) {   // development (-DSUMO_DBG_DUMP builds)
+  if (!E) FAIL(-1, "bad handle");
+  E->dbg_dump = dev_buf;
   return 0;
 }
 extern "C" int sumo_debug_fault(sumo_handle_t E, int env) {

@@ -42,7 +42,7 @@ class PPOModel(object):
             self.grads = torch.zeros(self.P + ppo_capi.NSTATS * 2, dtype=torch.float32, device=self.device)
             self.stats = torch.zeros(ppo_capi.NSTATS, dtype=torch.float64, device=self.device)
             self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
-            self.workspace = torch.empty(ppo_capi.lib().ppo_grad_workspace_bytes(D, A), dtype=torch.uint8, device=self.device)
+            self.workspace = torch.zeros(ppo_capi.lib().ppo_grad_workspace_bytes(D, A), dtype=torch.uint8, device=self.device)   # zeroed once: sumo_ppo.h
             self._graphs = {}
             self._static = None
             self._epoch_moments = None

@@ -25,6 +25,19 @@ for rep in range(3):
                     else:
                         print("rep %d run %d %s: %d entries differ; (env, t) first: %s" % (rep, ri, names[k], len(idx), [(int(j) // TT, int(j) % TT) for (j,) in idx[:6]]))
                     bad += 1
+                    if names[k] == "obs":       # which entries of the first differing observation, and by how much
+                        a_, j = idx[0]
+                        xo, yo = x[int(a_), int(j)].cpu().numpy(), y[int(a_), int(j)].cpu().numpy()
+                        w = np.nonzero(xo != yo)[0]
+                        print("   first differing obs (agent %d env %d t %d): entries %s, |diff| max %.3g; fused %s stepwise %s" % (
+                            a_, int(j) // TT, int(j) % TT, w[:12], np.abs(xo - yo).max(), xo[w[:4]], yo[w[:4]]))
+                        t0_ = int(j) % TT
+                        for ag in (0, 1):      # both agents' rows of that env and step: which blocks differ
+                            xa, ya = x[ag, int(j)].cpu().numpy(), y[ag, int(j)].cpu().numpy()
+                            wa = np.nonzero(xa != ya)[0]
+                            print("   agent %d env %d t %d: %d entries differ: %s; max |diff| %.3g" % (ag, int(j) // TT, t0_, len(wa), wa[:40], np.abs(xa - ya).max() if len(wa) else 0.0))
+                        ts = np.array([int(jj) % TT for _, jj in idx])
+                        print("   differing rows per step:", np.bincount(ts, minlength=TT))
                     if names[k] == "rewards":
                         X, Y = x[0].reshape(N, TT).cpu().numpy(), y[0].reshape(N, TT).cpu().numpy()
                         for a_, j in idx[:4]:
