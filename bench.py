@@ -161,6 +161,9 @@ def spider_segment(torch, dev, local_rank, args, hp):
            "waves_per_cu": int(160 * 1024 // env.engine.lds_bytes), "mean_contacts_per_forward": (st1["contacts"] - st0["contacts"]) / nf,
            "mean_newton_iters_per_forward": (st1["newton"] - st0["newton"]) / nf,
            "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env.model)}
+    if fused:
+        out.update(profile_rooflines("r03_spider", "sumo_rollout_kernel<%d, 0>" % env.model.nv, N, env.model, out["env_steps_per_s"],
+                                     e0.elapsed_time(e1), N * K))
     env.close()
     return out
 
@@ -195,17 +198,66 @@ def recurrent_segment(torch, dev, local_rank, args, hp):
     advance(args.state_warmup)
     r.join_groups()
     torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     advance(K)
     r.join_groups()
+    e1.record()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     check_rollout(env, fused)
-    out = {"env_id": env_id, "envs": N, "steps": K, "policy": "lstm(128), shared value head", "opponent_pool": P,
+    out = {"env_id": env_id, "envs": N, "steps": K, "policy": "lstm(128), shared value head", "opponent_pool": P, "gpu_ms": e0.elapsed_time(e1),
            "env_steps_per_s": N * K / dt, "ms_per_step": dt / K * 1e3, "rollout_path": "fused" if fused else "stepwise",
            "note": "1024 envs leave half of the chip's 2048 wave slots empty: the launch lasts as long as its slowest env's chain of steps"}
+    if fused:
+        rf = profile_rooflines("r03_rec1024", "sumo_rollout_kernel<%d, 1>" % env.model.nv, N, env.model, out["env_steps_per_s"], out["gpu_ms"], N * K)
+        rf["roofline"]["algorithmic_bytes_per_env_step_note"] = "env record only; the recurrent states add 2 x 2 x 1 KB per env step"
+        out.update(rf)
     env.close()
     return out
+
+
+def profile_rooflines(prefix, kernel_sub, envs, model, env_steps_per_s, launch_ms, steps_per_launch):
+    """HBM / ALU roofline objects of a secondary config from its rocprofv3 summaries profiles/<prefix>_pmc_{traffic,sq}.json
+    (tools/profile_r03.sh; quoted only if the file is for this kernel variant and env count) and the live launch time."""
+    B = algorithmic_bytes_per_env_step(model)
+    out = {}
+
+    def load(name):
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return pj if kernel_sub in pj["kernel"] and pj["envs"] == envs else None
+        except Exception:
+            return None
+    tr, sq = load(prefix + "_pmc_traffic.json"), load(prefix + "_pmc_sq.json")
+    ach = B * steps_per_launch / (launch_ms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                       "traffic": None if tr is None else tr["traffic_bytes_per_env_step"] * steps_per_launch,
+                       "traffic_source": None if tr is None else "profiles/%s_pmc_traffic.json" % prefix, "kernel": kernel_sub,
+                       "kernel_ms": launch_ms, "algorithmic_bytes_per_env_step": B, "env_steps_per_launch": steps_per_launch}
+    if sq is not None:
+        out["roofline_alu"] = alu_roofline(sq["derived"], env_steps_per_s, kernel_sub, "profiles/%s_pmc_sq.json" % prefix)
+    return out
+
+
+def alu_roofline(d, env_steps_per_s, kernel, source):
+    """ALU side of a physics kernel from its SQ counter summary: f64 flops as ISSUED over 64 lanes and the part that lands on
+    active lanes (x mean active lanes / 64), both scaled by the live env-step rate; VALU issue share of SIMD time with every
+    instruction priced at 4 cycles and with f64 arithmetic at 4, everything else at 2 (MI355X_MICROARCH.md)."""
+    fl = d["f64_flops_issued_per_env_step"]
+    tf = fl * env_steps_per_s / 1e12
+    o = {"bound": "valu_f64", "kernel": kernel, "achieved": tf, "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TF,
+         "f64_flops_issued_per_env_step": fl, "valu_issue_frac": d["valu_issue_frac"], "valu_issue_frac_priced": d.get("valu_issue_frac_priced"),
+         "valu_active_frac_of_wave_cycles": d.get("active_valu_frac"), "waiting_frac_of_wave_cycles": d.get("wait_any_frac"),
+         "mean_active_lanes": d.get("mean_active_lanes"), "valu_insts_per_forward": d.get("valu_insts_per_forward_per_wave"),
+         "wave_cycles_per_forward": d.get("wave_cycles_per_forward"), "source": source,
+         "note": "flops = (ADD+MUL+TRANS + 2 FMA) f64 wave-instructions x 64 lanes per env step from the profile, times the live rate"}
+    if d.get("f64_flops_on_active_lanes_per_env_step") is not None:
+        tfa = d["f64_flops_on_active_lanes_per_env_step"] * env_steps_per_s / 1e12
+        o["achieved_on_active_lanes"] = tfa
+        o["frac_on_active_lanes"] = tfa / F64_VALU_PEAK_TF
+    return o
 
 
 def check_rollout(env, fused):
@@ -441,13 +493,13 @@ def main():
             except Exception:
                 return None
         traffic, traffic_src = None, None
-        for cand in ("r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01f_pmc_traffic.json"):
+        for cand in ("r03_ant_pmc_traffic.json", "r02c_pmc_traffic.json", "r02b_pmc_traffic.json", "r02_pmc_traffic.json", "r01f_pmc_traffic.json"):
             pj = profile_json(cand)
             if pj is not None:          # per env step in the profile, scaled to this launch's env steps
                 traffic, traffic_src = pj["traffic_bytes_per_env_step"] * steps_per_launch, "profiles/" + cand
                 break
         sq, sq_src = None, None
-        for cand in ("r02c_pmc_sq.json", "r02b_pmc_sq.json", "r02_pmc_sq.json"):
+        for cand in ("r03_ant_pmc_sq.json", "r02c_pmc_sq.json", "r02b_pmc_sq.json", "r02_pmc_sq.json"):
             sq = profile_json(cand)
             if sq is not None:
                 sq_src = "profiles/" + cand
@@ -469,7 +521,14 @@ def main():
                        "envs_per_gpu": N, "env_groups_per_gpu": env.groups, "total_envs": N * world, "parallelism": "env-shard x%d" % world,
                        "mean_contacts_per_forward": (st1["contacts"] - st0["contacts"]) / nfwd,
                        "mean_newton_iters_per_forward": (st1["newton"] - st0["newton"]) / nfwd,
-                       "lds_bytes_per_env": env.engine.lds_bytes},
+                       "lds_bytes_per_env": env.engine.lds_bytes,
+                       # contact-generation fidelity accounting (DESIGN.md deviations 1-2), sampled in the forward evaluation that opens
+                       # each env step: capsule-box calls with 3 active contacts (MuJoCo: <= 2) and contacts on a border rod beyond the
+                       # cylinder's flat end (rods collide as capsules), per million sampled forwards; contacts dropped for lack of room
+                       "contact_fidelity": {"sampled_forwards": total_steps / max(1, world),
+                                            "capsule_box_3_per_million": 1e6 * (st1.get("capsule_box_3", 0) - st0.get("capsule_box_3", 0)) / max(1.0, total_steps / max(1, world)),
+                                            "rod_endcap_per_million": 1e6 * (st1.get("rod_endcap", 0) - st0.get("rod_endcap", 0)) / max(1.0, total_steps / max(1, world)),
+                                            "dropped_contacts": st1["dropped"] - st0["dropped"]}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": B,
@@ -478,19 +537,20 @@ def main():
                          "note": "latency/ALU-bound physics: ~20 forward-dynamics solves per 2.4 KB of state traffic"},
         }
         if sq is not None:
-            # ALU side of the physics kernel: the f64 instruction mix counted by the SQ (flops as ISSUED over 64 lanes; the
-            # kernel keeps 28-44 of them busy) scaled by the live env-step rate, and the share of SIMD issue time the VALU holds
-            d = sq["derived"]
-            fl = d["f64_flops_issued_per_env_step"]
-            tf = fl * value / max(1, world) / 1e12
-            out["roofline_alu"] = {"bound": "valu_f64", "kernel": kernel_name, "achieved": tf, "peak": F64_VALU_PEAK_TF,
-                                   "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TF, "f64_flops_issued_per_env_step": fl,
-                                   "valu_issue_frac": d["valu_issue_frac"], "valu_active_frac_of_wave_cycles": d.get("active_valu_frac"),
-                                   "waiting_frac_of_wave_cycles": d.get("wait_any_frac"), "mean_active_lanes": d.get("mean_active_lanes"),
-                                   "source": sq_src,
-                                   "note": "flops = (ADD+MUL+TRANS + 2 FMA) f64 wave-instructions x 64 lanes per env step from the profile, times the live rate"}
+            out["roofline_alu"] = alu_roofline(sq["derived"], value / max(1, world), kernel_name, sq_src)
         if mfma is not None:
             out["roofline_mfma"] = dict(mfma, bound="mfma", peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", dtype="f32 (v_mfma_f32_16x16x4_f32)")
+            # the same kernels by rocprofv3 counters (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32; tools/profile_r03.sh mfma)
+            for kn, fn in (("ppo_grad_kernel", "r03_pmc_mfma_grad.json"), ("ppo_selfplay_kernel", "r03_pmc_mfma_selfplay.json")):
+                try:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    dd = pj["derived"]
+                    out["roofline_mfma"][kn]["counters"] = {
+                        "mfma_busy_frac_of_simd_time": dd.get("mfma_busy_frac_of_simd_time"), "mfma_tflops": dd.get("mfma_tflops_at_2p4ghz"),
+                        "frac_of_peak": dd.get("frac_of_f32_mfma_peak_157p3"), "kernel_us": dd["kernel_cycles"] / 2.4e3,
+                        "counted_over_algorithmic_flops": dd.get("counted_over_algorithmic"), "source": "profiles/" + fn}
+                except Exception:
+                    pass
         if spider is not None:
             out["config"]["spider"] = spider
         if recurrent is not None:

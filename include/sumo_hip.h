@@ -149,6 +149,19 @@ int sumo_debug_forward(sumo_handle_t h, const double* ctrl, double* qacc, int32_
  * are partly advanced: reset before continuing.  out4 (HOST, may be NULL): {abort flag, tickets drawn, tickets of the launch
  * (E x K), hand-over mismatches since creation}.  Runner.run (device mode) and bench.py call this after every rollout. */
 int sumo_rollout_status(sumo_handle_t h, int64_t* out4);
+/* 1 if this engine runs the static-Layout kernel variants: for the flagship scene (RoboSumo-Ant-vs-Ant-v0, default settings) the LDS
+ * layout, the model's dimensions / table offsets and the derived-table offsets are compile-time constants of the per-step and the fused
+ * rollout kernels (csrc/layout_static.h, generated by tools/gen_static_layout.py from the engine's own host code; sumo_create compares
+ * the scene's runtime values with the tables word for word).  Results are bit-identical to the runtime-Layout variants every other scene
+ * uses (SUMO_STATIC_LAYOUT=0 forces those); 0 otherwise. */
+int sumo_static_layout(sumo_handle_t h);
+/* development, host only (no device): the Layout / the model's and the derived tables' integer members the engine computes for a scene
+ * (tools/gen_static_layout.py) */
+int sumo_debug_layout(const void* model_blob, size_t nbytes, int32_t* out, int cap);
+int sumo_debug_model_ints(const void* model_blob, size_t nbytes, int32_t* out, int cap, int32_t* aux_out, int aux_cap);
+/* development (-DSUMO_DBG_DUMP builds): device buffer [20][8][64] float64 that receives intermediate vectors of env 0's forward
+ * evaluations (tools/dump_diff.py); NULL = off */
+int sumo_debug_dump(sumo_handle_t h, double* dev_buf);
 /* development / tests: the first hand-over of env `env` in the following fused launches carries a wrong checksum (-1 = off) */
 int sumo_debug_fault(sumo_handle_t h, int env);
 /* device-side statistics accumulated since creation: forward calls, newton iterations, contacts, efc rows,

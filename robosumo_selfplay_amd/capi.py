@@ -71,6 +71,8 @@ def lib():
         L.sumo_rollout_status.restype = i32
         L.sumo_debug_fault.argtypes = [vp, i32]
         L.sumo_debug_fault.restype = i32
+        L.sumo_static_layout.argtypes = [vp]
+        L.sumo_static_layout.restype = i32
         L.sumo_profile.restype = i32
         for n in ("sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps", "sumo_rollout_steps_lstm", "sumo_get_state",
                   "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_set_adjust_z", "sumo_set_state", "sumo_debug_forward", "sumo_stats"):
@@ -81,7 +83,7 @@ def lib():
 
 EXPORTS = ("sumo_last_error", "sumo_create", "sumo_destroy", "sumo_dims", "sumo_reset", "sumo_step", "sumo_rollout_steps",
            "sumo_rollout_steps_lstm", "sumo_set_cfrc_mode", "sumo_get_cfrc_ext", "sumo_set_adjust_z", "sumo_get_state", "sumo_set_state", "sumo_debug_forward", "sumo_stats", "sumo_profile", "sumo_debug_trace",
-           "sumo_rollout_status", "sumo_debug_fault")
+           "sumo_rollout_status", "sumo_debug_fault", "sumo_static_layout", "sumo_debug_layout", "sumo_debug_model_ints", "sumo_debug_dump")
 
 
 def _np(a):
@@ -203,6 +205,10 @@ class Engine:
         o = np.zeros(4, np.int64)
         _chk(lib().sumo_rollout_status(self.h, _np(o)))
         return dict(aborted=int(o[0]), tickets_drawn=int(o[1]), tickets=int(o[2]), mismatches=int(o[3]))
+
+    def static_layout(self):
+        """True if this engine runs the static-Layout kernel variants (flagship scene, default settings; include/sumo_hip.h)."""
+        return lib().sumo_static_layout(self.h) == 1
 
     def debug_fault(self, env):
         """Tests: make the first hand-over of ``env`` in the following fused launches carry a wrong checksum (-1 = off)."""

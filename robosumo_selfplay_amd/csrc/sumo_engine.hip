@@ -72,6 +72,8 @@ struct Aux {  // derived integer tables (built on the host in build_aux)
   int nwp, wrounds, arounds;  // pairs with a static world geom (listed first), rounds of 64 for them / for the rest
 };
 
+#define AUX_NINTS ((int)((offsetof(Aux, arounds) + sizeof(int) - offsetof(Aux, ndepth)) / sizeof(int)))   /* the int members: ndepth .. arounds */
+
 struct Layout {  // LDS offsets in doubles unless noted
   int ld;        // leading dimension of H (odd)
   int mld, msize, d1;  // mass matrix: one dense block per agent tree, leading dim mld (odd); d1 = first dof of agent 1
@@ -99,6 +101,13 @@ struct Layout {  // LDS offsets in doubles unless noted
   int stat_i;    // static int tables: ctype[nc] | cbody[nc] | chain[2*nbody] | chlen_agent[nbody]
   int total_bytes;
 };
+
+// Compile-time copy of the Layout of the flagship scene (Ant-vs-Ant, default settings), generated by tools/gen_static_layout.py from
+// build_layout() itself (sumo_debug_layout).  With it every `c.L.field` of the hot kernels is an immediate: LDS addresses become
+// `lane-dependent base + constant offset` (one shift per lane index instead of an add per array), and the ~60 wave-uniform words of
+// the runtime Layout no longer compete for the 102 SGPRs.  sumo_create compares the scene's runtime Layout with this table word
+// for word and uses the static kernel variants only on an exact match (any other scene / setting: the runtime-Layout variants).
+#include "layout_static.h"
 
 struct StepArgs {
   double* state;       // [N][state_stride]
@@ -440,11 +449,12 @@ struct Params {  // lives in device memory; read through scalar / per-lane loads
   double adjust_z;          // Agent._adjust_z (agents.py:33,155-161): added to the z an agent REPORTS -- observations and lose test; 0 in training
 };
 
-template <int NV_>
+template <int NV_, class LT_ = Layout>
 struct Ctx {
+  typedef LT_ LT;
   static constexpr int NV = NV_;                                  // compile-time nv (register-resident factorisation)
   static constexpr int EPL = (NV_ * (NV_ + 1) / 2 + WAVE - 1) / WAVE;
-  Layout L;             // LDS layout, copied from Params once per launch (wave-uniform -> SGPRs)
+  LT L;                 // LDS layout: the runtime Layout copied from Params once per launch (wave-uniform -> SGPRs), or the static table
   const LaneRec* kp;    // this lane's constant record (device memory, L1-resident); phases copy the fields they need
   const int* prp;       // this lane's packed pair records / bounds: element r*64
   const float* pbp;
@@ -473,6 +483,18 @@ struct Ctx {
 #endif
 };
 
+// The model / aux views of a context: the runtime structs in device memory, or -- static-Layout variants -- objects whose integer
+// members are compile-time constants of the flagship scene (layout_static.h) and whose three pointers are read from Params.
+template <class C>
+__device__ __forceinline__ decltype(auto) model_view(const C& c) {
+  if constexpr (std::is_same<typename C::LT, Layout>::value) return (const sumo_model_t&)c.P->mdl;
+  else { ModelAntAnt m; m.ibase = c.P->mdl.ibase; m.fbase = c.P->mdl.fbase; m.tatami_size = c.P->mdl.tatami_size; return m; }
+}
+template <class C>
+__device__ __forceinline__ decltype(auto) aux_view(const C& c) {
+  if constexpr (std::is_same<typename C::LT, Layout>::value) return (const Aux&)c.P->aux;
+  else { AuxAntAnt x; x.ai = c.P->aux.ai; x.af = c.P->aux.af; x.pic = c.P->aux.pic; return x; }
+}
 #define S(off) (c.sm + c.L.off)
 // Per-lane constants are re-read at the start of each phase instead of being pinned in registers for the whole launch
 // (the optimisation barrier stops the compiler from hoisting the loads back to kernel entry): this keeps the kernel
@@ -593,8 +615,8 @@ __device__ __forceinline__ void gather_up(C& c, double* arr) {
 
 template <class C>
 __device__ __forceinline__ void position_velocity(C& c) {
-  const sumo_model_t& mdl = c.P->mdl;
-  const Aux& aux = c.P->aux;
+  const auto& mdl = model_view(c);
+  const auto& aux = aux_view(c);
   const int lane = c.lane;
   const int nb = mdl.nbody, nv = mdl.nv;
   if (lane == 0) {
@@ -1098,7 +1120,7 @@ __device__ __forceinline__ void collision(C& c) {
   // contact-generation fidelity accounting (Ctx::st_cb3), out of line (the narrow-phase loop above stays as it was) and SAMPLED: the
   // forward evaluation that opens an env step, 1 in frame_skip x 4 RK stages = 20 (every forward: +0.9 % on the bench; sampled: nil)
   if ((c.st_forward - 1) % 20 == 0) {
-    const sumo_model_t& mdl = c.P->mdl;
+    const auto& mdl = model_view(c);
     const int r = fidelity_count(S(cond), c.si + c.L.con_b, ncon, lane, MI(pair_geom2), MI(geom_type), MF(geom_pos), MF(geom_quat), MF(geom_size));
     c.st_cb3 += r & 0xFFFF;
     c.st_rodcap += r >> 16;
@@ -1142,7 +1164,7 @@ __device__ __forceinline__ double row_params(double timestep, const double* solr
 
 template <class C>
 __device__ __forceinline__ void make_constraint(C& c) {
-  const sumo_model_t& mdl = c.P->mdl;
+  const auto& mdl = model_view(c);
   KCONSTS();
   const int lane = c.lane, nv = mdl.nv;
   // ---- Jacobian pool allocation (contact order): one 3x8 half per moving body of the contact
@@ -1556,8 +1578,8 @@ __device__ __forceinline__ double solver_cost(C& c, double Ma_i, double x_i) {
 // factorisation does not share a loop (and its spills) with the common tree-sparse one
 template <bool TREE, class C>
 __device__ __forceinline__ void newton_solve(C& c) {
-  const sumo_model_t& mdl = c.P->mdl;
-  const Aux& aux = c.P->aux;
+  const auto& mdl = model_view(c);
+  const auto& aux = aux_view(c);
   const int lane = c.lane, nv = mdl.nv, nefc = c.nefc, ncon = c.ncon, nrow = 4 * c.ncon;
   const double tol = MF(opt)[SUMO_OPT_TOLERANCE];
   const int maxiter = (int)MF(opt)[SUMO_OPT_ITERATIONS];
@@ -1785,7 +1807,7 @@ __device__ __forceinline__ void newton_solve(C& c) {
 // ---- mj_forward ----------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void forward(C& c) {
-  const sumo_model_t& mdl = c.P->mdl;
+  const auto& mdl = model_view(c);
   const int lane = c.lane, nv = mdl.nv;
   c.st_forward++;
   DUMP(0, S(qpos), mdl.nq); DUMP(1, S(qvel), nv); DUMP(2, S(ctrl), mdl.nu); DUMP(7, S(warm), nv);
@@ -1880,7 +1902,7 @@ __device__ __forceinline__ void integrate_pos(C& c, double* qpos, const double* 
 // reference turns the resulting warning into a MujocoException, mujoco-py/mujoco_py/builder.py:351-369).  Wave-uniform result.
 template <class C>
 __device__ __forceinline__ int state_is_bad(C& c) {
-  const sumo_model_t& mdl = c.P->mdl;
+  const auto& mdl = model_view(c);
   const int lane = c.lane;
   bool bad = false;
   for (int i = lane; i < mdl.nq; i += WAVE) bad |= !(fabs(S(qpos)[i]) <= 1e10);   // NaN fails the comparison too
@@ -1892,7 +1914,7 @@ __device__ __forceinline__ int state_is_bad(C& c) {
 // the last stage's qacc.
 template <class C>
 __device__ __forceinline__ void mj_steps(C& c, int nsteps) {
-  const sumo_model_t& mdl = c.P->mdl;
+  const auto& mdl = model_view(c);
   const int lane = c.lane, nq = mdl.nq, nv = mdl.nv;
   const double h = MF(opt)[SUMO_OPT_TIMESTEP];
   double q0 = 0, v0 = 0, accv = 0, acca = 0;   // this lane's entry of the step's start state and of the RK4 accumulators
@@ -1954,7 +1976,7 @@ __device__ __forceinline__ double rng_uniform(uint64_t seed, uint32_t reset_coun
 // sumo.py:232-253 with a counter RNG; state ends up in LDS (qpos, qvel, warm)
 template <class C>
 __device__ __forceinline__ void reset_state(C& c, uint64_t seed, uint32_t rc) {
-  const sumo_model_t& mdl = c.P->mdl;
+  const auto& mdl = model_view(c);
   const int lane = c.lane, nq = mdl.nq, nv = mdl.nv;
   if (lane < nq) S(qpos)[lane] = MF(qpos0)[lane];
   SYNC();
@@ -2010,7 +2032,7 @@ __device__ __forceinline__ void hand_store(T* p, T v) {
 
 template <bool COH = false, class C>
 __device__ __forceinline__ void write_obs(C& c, float* obs, int obs_stride, int num_steps) {
-  const sumo_model_t& mdl = c.P->mdl;
+  const auto& mdl = model_view(c);
   const double adjz = c.P->adjust_z;
   for (int idx = c.lane; idx < 2 * obs_stride; idx += WAVE) {
     int a = idx >= obs_stride, k = idx - a * obs_stride, o = 1 - a;
@@ -2056,10 +2078,10 @@ __device__ __forceinline__ float sumsq_f32_ctrl(const double* u, int n) {
 template <class C>
 __device__ __forceinline__ void ctx_init(C& c, const Params* P, double* smem) {
   c.P = P;
-  c.L = P->L;
+  if constexpr (std::is_same<typename C::LT, Layout>::value) c.L = P->L;
   c.sm = smem;
-  c.si = (int*)(smem + P->L.i_base);
-  c.sb = (unsigned char*)(smem + P->L.i_base);
+  c.si = (int*)(smem + c.L.i_base);
+  c.sb = (unsigned char*)(smem + c.L.i_base);
   c.lane = threadIdx.x;
   c.kp = P->lanes + c.lane;
   c.prp = P->pair_rec + c.lane;
@@ -2199,7 +2221,7 @@ __device__ __forceinline__ void poison_lds(const Params* P, int lane) {
 // (sumo_step_kernel) and the fused multi-step rollout launch (sumo_rollout_kernel).
 template <bool COH = false, class C, class SA>
 __device__ __forceinline__ void env_step_body(C& c, const SA& a, int e) {
-  const sumo_model_t& mdl = c.P->mdl;
+  const auto& mdl = model_view(c);
   const int lane = c.lane;
   if (a.trace && lane == 0) a.trace[4 * e] = wall_clock64();
   const unsigned rec_sum = load_state<COH>(c, a, e);
@@ -2343,9 +2365,12 @@ __device__ __forceinline__ void env_step_body(C& c, const SA& a, int e) {
   }
 }
 
-template <int NV>
+template <int SL> struct LayoutSel { typedef Layout type; };
+template <> struct LayoutSel<1> { typedef LayoutAntAnt type; };
+
+template <int NV, int SL = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE_OF(NV), SUMO_WPE_OF(NV)))) sumo_step_kernel(const Params* P, StepArgs a) {
-  Ctx<NV> c;
+  Ctx<NV, typename LayoutSel<SL>::type> c;
   ctx_init(c, P, smem_dyn);
   const int lane = c.lane;
   if ((int)blockIdx.x < a.rank_blocks) { sched_rank(a.rank_cost, a.N, a.rank_perm, blockIdx.x, lane); return; }
@@ -2420,7 +2445,7 @@ sumo_cfrc_kernel(const Params* P, StepArgs a, CfrcArgs q) {
   const int nc2 = c.ncon < ncon ? c.ncon : ncon;   // (make_constraint may have cut the list to the Jacobian pool)
   KCONSTS();
   double w[6] = {0, 0, 0, 0, 0, 0};
-  const int b = lane, ag = K.b_agent;
+  const int b = lane, ag = K.b_agent;   // one body per lane: build_aux refuses scenes with nbody > WAVE at sumo_create ("scene too large for one wavefront per env")
   if (b > 0 && b < nb) {
     const double* com = S(com) + 3 * ag;
     for (int ci = 0; ci < nc2; ci++) {
@@ -2540,7 +2565,7 @@ __device__ __forceinline__ void rollout_policy_phase(C& c, const SA& a, const RA
     pt_global(r.act)[slot0 * A + i] = act0; pt_global(r.act)[slot1 * A + i] = act1;
     float* ae = const_cast<float*>(a.actions) + (size_t)e * 2 * a.act_stride;
     hand_store<true>(ae + i, act0); hand_store<true>(ae + a.act_stride + i, act1);     // the env's action buffer (output only)
-    const sumo_model_t& mdl = c.P->mdl;
+    const auto& mdl = model_view(c);
     S(ctrl)[MI(agent_uadr)[0] + i] = (double)act0; S(ctrl)[MI(agent_uadr)[1] + i] = (double)act1;   // the step's control vector
   }
   if (lane == 0) {
@@ -2667,7 +2692,7 @@ __device__ __forceinline__ void rollout_policy_phase_lstm(C& c, const SA& a, con
     pt_global(r.act)[slot0 * A + lane] = act0; pt_global(r.act)[slot1 * A + lane] = act1;
     float* ae = const_cast<float*>(a.actions) + (size_t)e * 2 * a.act_stride;
     hand_store<true>(ae + lane, act0); hand_store<true>(ae + a.act_stride + lane, act1);
-    const sumo_model_t& mdl = c.P->mdl;
+    const auto& mdl = model_view(c);
     S(ctrl)[MI(agent_uadr)[0] + lane] = (double)act0; S(ctrl)[MI(agent_uadr)[1] + lane] = (double)act1;
   }
   if (lane == 0) {
@@ -2712,7 +2737,7 @@ struct RolloutLaunch { StepArgs a; RolloutArgs r; };
 // launch's abort flag (counted in sumo_stats[9]) and every wave drains.
 #define ROLLOUT_SPIN_LIMIT (1u << 22)   /* polls of ~0.5 us each */
 
-template <int NV, int POLICY>   // POLICY 0: MLP(64,64) policy / value nets; 1: LSTM(128) with shared value head
+template <int NV, int POLICY, int SL = 0>   // POLICY 0: MLP(64,64) policy / value nets; 1: LSTM(128) with shared value head; SL 1: static Layout
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE_OF(NV), SUMO_WPE_OF(NV))))
 sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
   // `launch_args` is read in place from the kernel-argument segment (second argument, 8-byte aligned right behind P) through a
@@ -2720,7 +2745,7 @@ sumo_rollout_kernel(const Params* P, RolloutLaunch launch_args) {
   (void)launch_args;
   typedef const RolloutLaunch PT_CAS* LaunchPtr;   // constant address space: every field read is a scalar load
   const LaunchPtr LP = (LaunchPtr)((const char PT_CAS*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(const Params*));
-  Ctx<NV> c;
+  Ctx<NV, typename LayoutSel<SL>::type> c;
   ctx_init(c, P, smem_dyn);
   for (;;) {
     LaunchPtr lp = launder_sptr(LP);
@@ -2877,6 +2902,7 @@ struct sumo_engine {
   long long rollout_tickets = -1;          // N * K of the most recent fused launch, -1: none yet
   int dbg_fault_env = -1;                  // sumo_debug_fault
   double* dbg_dump = nullptr;              // sumo_debug_dump (SUMO_DBG_DUMP builds)
+  int static_layout = 0;                   // 1: the scene's Layout equals the compile-time table (LayoutAntAnt): static kernel variants
   unsigned long long acked_faults = 0;     // stats[9] + stats[10] already reported by sumo_rollout_status
   long long sched_t = 0;                                                                     // step launches so far (in-kernel ranking)
   void* d_sort_tmp = nullptr;
@@ -3310,6 +3336,7 @@ static void build_layout(sumo_engine* E) {
   L.total_bytes = o * 8 + io * 4 + 16 * L.maxcon;
 }
 
+static int model_ints(const sumo_model_t* m, int32_t* out);
 extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, int device, sumo_handle_t* out) {
   if (!model_blob || !out || num_envs <= 0) FAIL(-1, "bad arguments");
   int ndev = 0;
@@ -3325,6 +3352,16 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
   rc = build_aux(E, ai, af, pic);
   if (rc != 0) { delete E; return rc; }
   build_layout(E);
+  {   // static kernel variants only when the runtime Layout IS the compile-time table (SUMO_STATIC_LAYOUT=0 switches them off)
+    static_assert(sizeof(Layout) % sizeof(int) == 0, "Layout is all ints");
+    const char* sl = getenv("SUMO_STATIC_LAYOUT");
+    int32_t mi[160];
+    const int nmi = model_ints(&E->hm, mi);
+    E->static_layout = sizeof(kLayoutAntAnt) == sizeof(Layout) && memcmp(&E->L, kLayoutAntAnt, sizeof(Layout)) == 0 &&
+                       sizeof(kModelAntAnt) == nmi * sizeof(int) && memcmp(mi, kModelAntAnt, sizeof(kModelAntAnt)) == 0 &&
+                       sizeof(kAuxAntAnt) == AUX_NINTS * sizeof(int) && memcmp(&E->aux.ndepth, kAuxAntAnt, sizeof(kAuxAntAnt)) == 0 &&
+                       !(sl && atoi(sl) == 0);
+  }
   if (E->L.maxefc > WAVE * (E->hm.nv <= 28 ? 2 : 4)) { int me = E->L.maxefc; delete E; FAIL(-24, "maxefc %d exceeds the rows a lane keeps in registers", me); }
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -3505,7 +3542,11 @@ extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_d
   }
   if (E->cfrc_mode)   // rne_post: the state this step starts from, for the second launch below
     HIPCHK(hipMemcpyAsync(E->d_state_prev, E->d_state, (size_t)E->N * E->state_stride * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  SUMO_DISPATCH_N(sumo_step_kernel, E, (hipStream_t)stream, a, nblocks);
+  if (E->static_layout && E->hm.nv == 28) {
+    dim3 g_(nblocks), b_(WAVE);
+    hipLaunchKernelGGL((sumo_step_kernel<28, 1>), g_, b_, (size_t)E->L.total_bytes, (hipStream_t)stream, E->d_params, a);
+  } else
+    SUMO_DISPATCH_N(sumo_step_kernel, E, (hipStream_t)stream, a, nblocks);
   HIPCHK(hipGetLastError());
   if (E->cfrc_mode) {
     CfrcArgs q;
@@ -3562,7 +3603,10 @@ static int rollout_launch(sumo_engine* E, const RolloutArgs& r, int policy, floa
   if (nw > (long long)E->N) nw = E->N;   // more waves than envs would only wait on each other's steps
   dim3 g_((unsigned)nw), b_(WAVE);
   size_t lds_ = (size_t)E->L.total_bytes;
-  if (!for_kernel_variant(E->hm.nv, [&](auto nvc_) {
+  if (E->static_layout && E->hm.nv == 28) {
+    if (policy == 1) hipLaunchKernelGGL((sumo_rollout_kernel<28, 1, 1>), g_, b_, lds_, st_, E->d_params, rl);
+    else hipLaunchKernelGGL((sumo_rollout_kernel<28, 0, 1>), g_, b_, lds_, st_, E->d_params, rl);
+  } else if (!for_kernel_variant(E->hm.nv, [&](auto nvc_) {
         if (policy == 1) hipLaunchKernelGGL((sumo_rollout_kernel<decltype(nvc_)::value, 1>), g_, b_, lds_, st_, E->d_params, rl);
         else hipLaunchKernelGGL((sumo_rollout_kernel<decltype(nvc_)::value, 0>), g_, b_, lds_, st_, E->d_params, rl);
       }))
@@ -3704,6 +3748,45 @@ extern "C" int sumo_rollout_status(sumo_handle_t E, int64_t* out4) {
   } else if (out4) for (int i = 0; i < 4; i++) out4[i] = o[i];
   return 0;
 }
+// host only (no device is touched): the Layout build_layout() computes for a scene, as ints in declaration order; returns the count.
+// tools/gen_static_layout.py turns it into csrc/layout_static.h.
+extern "C" int sumo_debug_layout(const void* model_blob, size_t nbytes, int32_t* out, int cap) {
+  if (!model_blob || !out) FAIL(-1, "bad arguments");
+  sumo_engine E;
+  E.blob.assign((const char*)model_blob, (const char*)model_blob + nbytes);
+  if (int rc = sumo_model_parse(&E.hm, E.blob.data(), nbytes)) FAIL(-4, "malformed model blob (%d)", rc);
+  std::vector<int> ai; std::vector<double> af; std::vector<signed char> pic;
+  if (int rc = build_aux(&E, ai, af, pic)) return rc;
+  build_layout(&E);
+  const int n = (int)(sizeof(Layout) / sizeof(int));
+  if (cap < n) FAIL(-2, "need room for %d ints", n);
+  memcpy(out, &E.L, sizeof(Layout));
+  return n;
+}
+// the integer members of the compiled model view (header dims, then the int / float table offsets in SUMO_*_TABLES order) and of Aux
+static int model_ints(const sumo_model_t* m, int32_t* out) {
+  int n = 0;
+  out[n++] = m->nq; out[n++] = m->nv; out[n++] = m->nu; out[n++] = m->nbody; out[n++] = m->njnt; out[n++] = m->ngeom; out[n++] = m->npair;
+  out[n++] = m->nagent; out[n++] = m->frame_skip; out[n++] = m->timestep_limit;
+#define X(name, len) out[n++] = m->o_##name;
+  SUMO_INT_TABLES(X)
+  SUMO_FLT_TABLES(X)
+#undef X
+  return n;
+}
+extern "C" int sumo_debug_model_ints(const void* model_blob, size_t nbytes, int32_t* out, int cap, int32_t* aux_out, int aux_cap) {
+  if (!model_blob || !out || !aux_out) FAIL(-1, "bad arguments");
+  sumo_engine E;
+  E.blob.assign((const char*)model_blob, (const char*)model_blob + nbytes);
+  if (int rc = sumo_model_parse(&E.hm, E.blob.data(), nbytes)) FAIL(-4, "malformed model blob (%d)", rc);
+  std::vector<int> ai; std::vector<double> af; std::vector<signed char> pic;
+  if (int rc = build_aux(&E, ai, af, pic)) return rc;
+  if (cap < 128 || aux_cap < AUX_NINTS) FAIL(-2, "buffers too small");
+  const int n = model_ints(&E.hm, out);
+  memcpy(aux_out, &E.aux.ndepth, AUX_NINTS * sizeof(int));
+  return n | (AUX_NINTS << 16);
+}
+extern "C" int sumo_static_layout(sumo_handle_t E) { return E ? E->static_layout : -1; }   // 1: this engine runs the static-Layout kernel variants
 extern "C" int sumo_debug_dump(sumo_handle_t E, double* dev_buf /* [2][8][64] or NULL */) {   // development (-DSUMO_DBG_DUMP builds)
   if (!E) FAIL(-1, "bad handle");
   E->dbg_dump = dev_buf;

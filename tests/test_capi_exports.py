@@ -71,3 +71,14 @@ def test_ppo_library_exports_every_declared_symbol():
         assert hasattr(L, n), n
     L.ppo_param_count.restype = ctypes.c_int
     assert L.ppo_param_count(121, 8) == 24529           # MLP(64,64) + copy value net on 121-d obs
+
+
+def test_static_layout_header_is_current():
+    """csrc/layout_static.h (compile-time Layout / model / aux constants of the flagship scene, used by the static kernel variants)
+    must equal what the engine's own host code computes for RoboSumo-Ant-vs-Ant-v0 -- otherwise sumo_create silently falls back to
+    the runtime-Layout kernels (results identical, ~5 % slower)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_static_layout.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]

@@ -188,6 +188,33 @@ def test_batch_independence_and_determinism(env_id):
     assert st["diverged"] == 0
 
 
+def test_static_layout_variants_match_runtime_layout(monkeypatch):
+    """The flagship scene runs kernel variants whose LDS layout / model dimensions / table offsets are compile-time constants
+    (csrc/layout_static.h); every other scene, and SUMO_STATIC_LAYOUT=0, the runtime-Layout variants.  Same bits either way."""
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SUMO_STATIC_LAYOUT", flag)
+        env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=96, seed=7)
+        assert env.engine.static_layout() == (flag == "1")
+        env.reset_device()
+        g = torch.Generator(device="cpu").manual_seed(0)
+        acts = torch.randn((12, 96, 2, 8), generator=g).to("cuda") * 1.5
+        for t in range(12):
+            obs, info, done, *_ = env.step_device(acts[t].contiguous())
+        torch.cuda.synchronize()
+        outs[flag] = (obs.cpu().numpy().copy(), info.cpu().numpy().copy(), env.engine.get_state(), env.stats())
+        env.close()
+    assert np.array_equal(outs["1"][0], outs["0"][0]) and np.array_equal(outs["1"][1], outs["0"][1])
+    for x, y in zip(outs["1"][2], outs["0"][2]):
+        assert np.array_equal(x, y)
+    for k in ("forward", "newton", "contacts", "efc"):
+        assert outs["1"][3][k] == outs["0"][3][k]
+    monkeypatch.delenv("SUMO_STATIC_LAYOUT")
+    env = SumoVecEnv("RoboSumo-Spider-vs-Spider-v0", num_envs=4, seed=1)
+    assert not env.engine.static_layout()
+    env.close()
+
+
 def test_vecenv_host_api_matches_reference_contract():
     """VecEnv surface of subproc_vec_env.py:35-116 / vec_env.py:29-138: shapes, dtypes, info keys, auto-reset."""
     env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=8, seed=42)
