@@ -162,7 +162,7 @@ def spider_segment(torch, dev, local_rank, args, hp):
            "mean_newton_iters_per_forward": (st1["newton"] - st0["newton"]) / nf,
            "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(env.model)}
     if fused:
-        out.update(profile_rooflines("r03_spider", "sumo_rollout_kernel<%d, 0>" % env.model.nv, N, env.model, out["env_steps_per_s"],
+        out.update(profile_rooflines("r03_spider", "sumo_rollout_kernel<%d, 0" % env.model.nv, N, env.model, out["env_steps_per_s"],
                                      e0.elapsed_time(e1), N * K))
     env.close()
     return out
@@ -211,7 +211,7 @@ def recurrent_segment(torch, dev, local_rank, args, hp):
            "env_steps_per_s": N * K / dt, "ms_per_step": dt / K * 1e3, "rollout_path": "fused" if fused else "stepwise",
            "note": "1024 envs leave half of the chip's 2048 wave slots empty: the launch lasts as long as its slowest env's chain of steps"}
     if fused:
-        rf = profile_rooflines("r03_rec1024", "sumo_rollout_kernel<%d, 1>" % env.model.nv, N, env.model, out["env_steps_per_s"], out["gpu_ms"], N * K)
+        rf = profile_rooflines("r03_rec1024", "sumo_rollout_kernel<%d, 1" % env.model.nv, N, env.model, out["env_steps_per_s"], out["gpu_ms"], N * K)
         rf["roofline"]["algorithmic_bytes_per_env_step_note"] = "env record only; the recurrent states add 2 x 2 x 1 KB per env step"
         out.update(rf)
     env.close()
@@ -488,7 +488,7 @@ def main():
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", name)))
                 kn = pj["kernel"]          # "sumo_step_kernel<28>" / "sumo_rollout_kernel<28, 0>" (nv, policy variant: 0 = the MLP one timed here)
-                ok = (("<%d>" % model.nv) in kn or ("<%d, 0>" % model.nv) in kn) and kernel_name in kn and pj["envs"] == env.group_size
+                ok = (("<%d>" % model.nv) in kn or ("<%d, 0" % model.nv) in kn) and kernel_name in kn and pj["envs"] == env.group_size
                 return pj if ok else None
             except Exception:
                 return None

@@ -152,8 +152,9 @@ int sumo_rollout_status(sumo_handle_t h, int64_t* out4);
 /* 1 if this engine runs the static-Layout kernel variants: for the flagship scene (RoboSumo-Ant-vs-Ant-v0, default settings) the LDS
  * layout, the model's dimensions / table offsets and the derived-table offsets are compile-time constants of the per-step and the fused
  * rollout kernels (csrc/layout_static.h, generated by tools/gen_static_layout.py from the engine's own host code; sumo_create compares
- * the scene's runtime values with the tables word for word).  Results are bit-identical to the runtime-Layout variants every other scene
- * uses (SUMO_STATIC_LAYOUT=0 forces those); 0 otherwise. */
+ * the scene's runtime values with the tables word for word).  Results agree with the runtime-Layout variants every other scene uses
+ * (SUMO_STATIC_LAYOUT=0 forces those) to float64 rounding -- a different compilation of the same source: literals change which multiply-add
+ * pairs are contracted -- and the oracle parity tests run on the static variants; 0 otherwise. */
 int sumo_static_layout(sumo_handle_t h);
 /* development, host only (no device): the Layout / the model's and the derived tables' integer members the engine computes for a scene
  * (tools/gen_static_layout.py) */

@@ -1362,26 +1362,32 @@ struct GradArgs {
 // waves idle -- and only wave 0 keeps the statistics, the head-bias and the logstd gradients.
 // (round 2's kernel: one wave per tile with the whole gradient of a net in its accumulators, 110 us per 16 384-row minibatch)
 // ---------------------------------------------------------------------------------------------------------
+#define GRAD_HS 68   /* activation-tile row stride of the gradient kernel (floats): 16-byte aligned rows, 128-bit reads conflict free */
 template <int KT, bool PI>
 __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int lane, int w) {
   const ParamLayout& L = a.L;
   const int XS = a.XS, D = L.D, A = L.A;
   const int i = lane & 15, kq = lane >> 4, tid = threadIdx.x;
   constexpr int K0 = 4 * KT;   // k-steps of the first layer (four features per step)
-  float *xb0 = lds, *xb1 = xb0 + 16 * XS, *h1 = xb1 + 16 * XS, *h2 = h1 + 16 * HS, *d1 = h2 + 16 * HS, *d2 = d1 + 16 * HS;
-  float* mydout = d2 + 16 * HS + w * 16 * 18;   // this wave's copy of the head deltas [16][18]
+  // Activation tiles: row stride GHS = 68 floats (16-byte aligned rows whose 128-bit reads are bank-conflict free: 68 = 4 mod 32).
+  // A-operand convention of this kernel: in k-step u the lane (i, kq) supplies feature kq * (K / 4) + u of row i -- each kq group
+  // covers a CONTIGUOUS quarter of the contraction range -- so a lane's A operands of a whole layer are K / 4 consecutive floats and
+  // come in as 128-bit LDS reads (4 per 64-wide layer instead of 16 dword reads); the resident B operands use the same permutation.
+  constexpr int GHS = GRAD_HS;
+  float *xb0 = lds, *xb1 = xb0 + 16 * XS, *h1 = xb1 + 16 * XS, *h2 = h1 + 16 * GHS, *d1 = h2 + 16 * GHS, *d2 = d1 + 16 * GHS;
+  float* mydout = d2 + 16 * GHS + w * 16 * 18;   // this wave's copy of the head deltas [16][18]
   const Net net = PI ? pi_net(a.params, L) : vf_net(a.params, L);
   const int cw = 16 * w + i;   // the hidden unit this lane's column stands for
   const bool col = i < net.nout;
-  // ---- resident B operands (lane (i, kq) holds B[k = 4u + kq][column i] of k-step u)
+  // ---- resident B operands (lane (i, kq) holds B[k = kq * (K / 4) + u][column i] of k-step u; the head-delta products keep 4u + kq)
   float bW0[K0], bW1[16], bW1T[16], bW2[16], bW2T[4];
 #pragma unroll
-  for (int u = 0; u < K0; u++) { const int k = 4 * u + kq; const float v = net.w0[(k < D ? k : D - 1) * H + cw]; bW0[u] = k < D ? v : 0.0f; }
+  for (int u = 0; u < K0; u++) { const int k = kq * K0 + u; const float v = net.w0[(k < D ? k : D - 1) * H + cw]; bW0[u] = k < D ? v : 0.0f; }
 #pragma unroll
   for (int u = 0; u < 16; u++) {
-    bW1[u] = net.w1[(4 * u + kq) * H + cw];
-    bW1T[u] = net.w1[cw * H + 4 * u + kq];                                   // (delta W1^T)[row][f] = sum_k delta[row][k] W1[f][k]
-    const float v = net.w2[(4 * u + kq) * net.nout + (col ? i : 0)];
+    bW1[u] = net.w1[(kq * 16 + u) * H + cw];
+    bW1T[u] = net.w1[cw * H + kq * 16 + u];                                  // (delta W1^T)[row][f] = sum_k delta[row][k] W1[f][k]
+    const float v = net.w2[(kq * 16 + u) * net.nout + (col ? i : 0)];
     bW2[u] = col ? v : 0.0f;
   }
 #pragma unroll
@@ -1424,30 +1430,45 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
     const int r0 = tile * 16;
     // ---- first layer, this wave's 16 units: two accumulation chains over the even / odd k-steps
     f32x4 acc = (f32x4){0, 0, 0, 0}, acc2 = (f32x4){0, 0, 0, 0};
+    {
+      const float4* xa = (const float4*)(xbuf + i * XS + kq * K0);
 #pragma unroll
-    for (int u = 0; u < K0; u += 2) {
-      acc = MFMA(xbuf[i * XS + 4 * u + kq], bW0[u], acc);
-      acc2 = MFMA(xbuf[i * XS + 4 * u + 4 + kq], bW0[u + 1], acc2);
+      for (int v = 0; v < KT; v++) {
+        const float4 q = xa[v];
+        acc = MFMA(q.x, bW0[4 * v], acc); acc2 = MFMA(q.y, bW0[4 * v + 1], acc2);
+        acc = MFMA(q.z, bW0[4 * v + 2], acc); acc2 = MFMA(q.w, bW0[4 * v + 3], acc2);
+      }
     }
     float h1v[4], h2v[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) { h1v[r] = fmaxf(acc[r] + acc2[r] + bias0, 0.0f); h1[(4 * kq + r) * HS + cw] = h1v[r]; }
+    for (int r = 0; r < 4; r++) { h1v[r] = fmaxf(acc[r] + acc2[r] + bias0, 0.0f); h1[(4 * kq + r) * GHS + cw] = h1v[r]; }
     __syncthreads();
     // ---- second layer
     acc = (f32x4){0, 0, 0, 0}; acc2 = (f32x4){0, 0, 0, 0};
+    {
+      const float4* ha = (const float4*)(h1 + i * GHS + kq * 16);
 #pragma unroll
-    for (int u = 0; u < 16; u += 2) {
-      acc = MFMA(h1[i * HS + 4 * u + kq], bW1[u], acc);
-      acc2 = MFMA(h1[i * HS + 4 * u + 4 + kq], bW1[u + 1], acc2);
+      for (int v = 0; v < 4; v++) {
+        const float4 q = ha[v];
+        acc = MFMA(q.x, bW1[4 * v], acc); acc2 = MFMA(q.y, bW1[4 * v + 1], acc2);
+        acc = MFMA(q.z, bW1[4 * v + 2], acc); acc2 = MFMA(q.w, bW1[4 * v + 3], acc2);
+      }
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) { h2v[r] = fmaxf(acc[r] + acc2[r] + bias1, 0.0f); h2[(4 * kq + r) * HS + cw] = h2v[r]; }
+    for (int r = 0; r < 4; r++) { h2v[r] = fmaxf(acc[r] + acc2[r] + bias1, 0.0f); h2[(4 * kq + r) * GHS + cw] = h2v[r]; }
     __syncthreads();
     request(tile + gridDim.x);   // the next tile's rows travel during the head and the backward half
     // ---- head (every wave) + loss deltas (D layout: rows 4kq+r, column i)
     f32x4 out = (f32x4){0, 0, 0, 0};
+    {
+      const float4* ha = (const float4*)(h2 + i * GHS + kq * 16);
 #pragma unroll
-    for (int u = 0; u < 16; u++) out = MFMA(h2[i * HS + 4 * u + kq], bW2[u], out);
+      for (int v = 0; v < 4; v++) {
+        const float4 q = ha[v];
+        out = MFMA(q.x, bW2[4 * v], out); out = MFMA(q.y, bW2[4 * v + 1], out);
+        out = MFMA(q.z, bW2[4 * v + 2], out); out = MFMA(q.w, bW2[4 * v + 3], out);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = r0 + 4 * kq + r;
@@ -1497,7 +1518,7 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
     wave_sync();
     // ---- head weight gradient, rows 16w .. 16w+15: gW2 += h2[:, slice]^T dhead
 #pragma unroll
-    for (int s_ = 0; s_ < 4; s_++) { const int row = 4 * s_ + kq; gW2 = MFMA(h2[row * HS + cw], mydout[row * 18 + i], gW2); }
+    for (int s_ = 0; s_ < 4; s_++) { const int row = 4 * s_ + kq; gW2 = MFMA(h2[row * GHS + cw], mydout[row * 18 + i], gW2); }
     // ---- dh2[:, slice] = dhead W2[slice, :]^T, masked by h2 > 0
     acc = (f32x4){0, 0, 0, 0};
     {
@@ -1507,31 +1528,35 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
         if (u < nk) acc = MFMA(mydout[i * 18 + 4 * u + kq], bW2T[u], acc);
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) { const float d = h2v[r] > 0.0f ? acc[r] : 0.0f; d2[(4 * kq + r) * HS + cw] = d; gb1 += d; }
+    for (int r = 0; r < 4; r++) { const float d = h2v[r] > 0.0f ? acc[r] : 0.0f; d2[(4 * kq + r) * GHS + cw] = d; gb1 += d; }
     __syncthreads();
     // ---- gW1[:, slice] += h1^T d2[:, slice]
 #pragma unroll
     for (int s_ = 0; s_ < 4; s_++) {
       const int row = 4 * s_ + kq;
-      const float b = d2[row * HS + cw];
+      const float b = d2[row * GHS + cw];
 #pragma unroll
-      for (int ft = 0; ft < 4; ft++) gW1[ft] = MFMA(h1[row * HS + ft * 16 + i], b, gW1[ft]);
+      for (int ft = 0; ft < 4; ft++) gW1[ft] = MFMA(h1[row * GHS + ft * 16 + i], b, gW1[ft]);
     }
     // ---- dh1[:, slice] = d2 W1[slice, :]^T, masked by h1 > 0 (only this wave reads its slice of d1 back)
     acc = (f32x4){0, 0, 0, 0}; acc2 = (f32x4){0, 0, 0, 0};
+    {
+      const float4* da = (const float4*)(d2 + i * GHS + kq * 16);
 #pragma unroll
-    for (int u = 0; u < 16; u += 2) {
-      acc = MFMA(d2[i * HS + 4 * u + kq], bW1T[u], acc);
-      acc2 = MFMA(d2[i * HS + 4 * u + 4 + kq], bW1T[u + 1], acc2);
+      for (int v = 0; v < 4; v++) {
+        const float4 q = da[v];
+        acc = MFMA(q.x, bW1T[4 * v], acc); acc2 = MFMA(q.y, bW1T[4 * v + 1], acc2);
+        acc = MFMA(q.z, bW1T[4 * v + 2], acc); acc2 = MFMA(q.w, bW1T[4 * v + 3], acc2);
+      }
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) { const float d = h1v[r] > 0.0f ? acc[r] + acc2[r] : 0.0f; d1[(4 * kq + r) * HS + cw] = d; gb0 += d; }
+    for (int r = 0; r < 4; r++) { const float d = h1v[r] > 0.0f ? acc[r] + acc2[r] : 0.0f; d1[(4 * kq + r) * GHS + cw] = d; gb0 += d; }
     wave_sync();
     // ---- gW0[:, slice] += x^T d1[:, slice]
 #pragma unroll
     for (int s_ = 0; s_ < 4; s_++) {
       const int row = 4 * s_ + kq;
-      const float b = d1[row * HS + cw];
+      const float b = d1[row * GHS + cw];
 #pragma unroll
       for (int ft = 0; ft < KT; ft++) gW0[ft] = MFMA(xbuf[row * XS + ft * 16 + i], b, gW0[ft]);
     }
@@ -1576,7 +1601,7 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
   }
 }
 
-#define GRAD_LDS_FLOATS(XS) (2 * 16 * (XS) + 4 * 16 * HS + 4 * 16 * 18)
+#define GRAD_LDS_FLOATS(XS) (2 * 16 * (XS) + 4 * 16 * GRAD_HS + 4 * 16 * 18)
 // Ant (KT = 8): 255 registers, two workgroups per CU.  The wider first layers of the Bug / Spider nets (KT = 11 / 14: 44 / 56 resident
 // B operands and as many accumulators) get the whole register file of a SIMD instead of spilling: one workgroup per CU.
 template <int KT>
@@ -1657,7 +1682,7 @@ extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, i
   GradArgs a;
   a.params = params; a.obs = obs; a.actions = actions; a.adv = adv_mb; a.returns = returns; a.oldnlp = old_neglogp; a.weight = is_weight;
   // the staged tile has the variant's full width (16 KT columns, zeros beyond ob_dim): no guards inside the tile loop
-  a.idx = idx; a.n = n; a.obs_stride = obs_stride; a.XS = x_stride(16 * (KT <= 8 ? 8 : (KT <= 11 ? 11 : 14))); a.inv_count = (float)inv_count; a.cliprange = cliprange;
+  a.idx = idx; a.n = n; a.obs_stride = obs_stride; a.XS = 16 * (KT <= 8 ? 8 : (KT <= 11 ? 11 : 14)) + 4;   /* 132 / 180 / 228 floats: rows 16-byte aligned, 128-bit A-operand reads conflict free */ a.inv_count = (float)inv_count; a.cliprange = cliprange;
   a.ent_coef = ent_coef; a.vf_coef = vf_coef; a.log_ratio = log_ratio_out; a.L = make_layout(ob_dim, ac_dim);
   int ntiles = (n + 15) / 16;
   int nblocks = ntiles;      // workgroups per net; a workgroup (4 waves) takes the tiles blockIdx.x, blockIdx.x + nblocks, ...

@@ -12,10 +12,10 @@ for W in "$@"; do
   rm -rf $O; mkdir -p $O
   P="python3 tools/prof_workload.py $W --steps $K --launches 3"
   case $W in
-    ant)     KS="sumo_rollout_kernel<28, 0>"; ENVS=4096;;
-    spider)  KS="sumo_rollout_kernel<44, 0>"; ENVS=4096;;
-    rec1024) KS="sumo_rollout_kernel<28, 1>"; ENVS=1024;;
-    rec4096) KS="sumo_rollout_kernel<28, 1>"; ENVS=4096;;
+    ant)     KS="sumo_rollout_kernel<28, 0,"; ENVS=4096;;
+    spider)  KS="sumo_rollout_kernel<44, 0,"; ENVS=4096;;
+    rec1024) KS="sumo_rollout_kernel<28, 1,"; ENVS=1024;;
+    rec4096) KS="sumo_rollout_kernel<28, 1,"; ENVS=4096;;
     mfma)    KS="ppo_grad_kernel"; ENVS=0;;
   esac
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- $P > $O/stats.log 2>&1 || exit 11
