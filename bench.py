@@ -333,7 +333,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("BENCH_BACKEND", "nccl")      # "nccl" is RCCL; "gloo" only to rehearse N>1 on a 1-GPU box
+        backend = os.environ.get("BENCH_BACKEND") or os.environ.get("SUMO_DIST_BACKEND") or "nccl"   # "nccl" is RCCL; "gloo" only to rehearse N>1 on a 1-GPU box
         ndev = torch.cuda.device_count()
         local_rank = local_rank % max(1, ndev)
         torch.cuda.set_device(local_rank)

@@ -172,8 +172,12 @@ int ppo_vtrace(const float* rewards, const float* values, const float* neglogp, 
                float* ratio, void* stream);
 
 /* minibatch rows are data rows idx[0..n) (idx may be NULL = identity).  moments double[3] = {sum adv, sum adv^2, n}
- * with adv = returns - values.  Deterministic (fixed summation order).  ppo_adv_moments keeps its per-block partial sums in
- * library-owned device memory: at most one call in flight per device and process (n <= 1 048 576). */
+ * with adv = returns - values.  Deterministic (fixed summation order), any n.  ppo_adv_moments_ws keeps its per-block partial sums
+ * and arrival counter in the caller's workspace (ppo_adv_moments_workspace_bytes() bytes, zero-initialised once; one call in flight per
+ * workspace): models stepping concurrently on different streams do not share state.  ppo_adv_moments is the convenience form on
+ * library-owned workspaces handed out round robin (16; one device per process). */
+size_t ppo_adv_moments_workspace_bytes(void);
+int ppo_adv_moments_ws(const float* returns, const float* values, const int32_t* idx, int n, double* moments, void* workspace, void* stream);
 int ppo_adv_moments(const float* returns, const float* values, const int32_t* idx, int n, double* moments, void* stream);
 int ppo_adv_normalize(const float* returns, const float* values, const int32_t* idx, int n, const double* moments,
                       float* adv_out, void* stream);

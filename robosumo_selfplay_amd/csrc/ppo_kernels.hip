@@ -1250,22 +1250,18 @@ extern "C" int ppo_vtrace(const float* rewards, const float* values, const float
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// advantage normalisation (model.py:180-185)
-// ---------------------------------------------------------------------------------------------------------
-// Blocks of 4096 rows (every thread's four gathers in flight at once), per-block partial sums in a fixed order, and the last
-// block to arrive adds the partials in block order: deterministic like the single-block version it replaces (41 us for a
-// 16 384-row minibatch: four dependent rounds of random gathers), one round of gathers deep.  The partials and the arrival
-// counter live in module-level device memory: one ppo_adv_moments in flight per device and process (the PPO step is a chain).
+// Advantage moments of a minibatch: blocks of 1024 threads sum grid-strided 4096-row chunks, write their partials (sc1, visible to every
+// XCD) into the CALLER's workspace and count themselves in; the last block adds the partials in block order (deterministic).  The
+// workspace (ppo_adv_moments_workspace_bytes; its arrival counter zero-initialised once, left at zero by every call) belongs to the
+// caller -- one model, one stream -- so two models stepping on different streams do not share state (round 2 kept it in module-level
+// device memory).  Any n: a block takes the chunks blockIdx.x, blockIdx.x + gridDim.x, ...
 #define ADV_MAX_BLOCKS 256
-__device__ double g_adv_part[2 * ADV_MAX_BLOCKS];
-__device__ unsigned int g_adv_arrived;
-__global__ void __launch_bounds__(1024) ppo_adv_moments_kernel(const float* ret, const float* val, const int32_t* idx, int n, double* mom) {
+struct AdvWs { double part[2 * ADV_MAX_BLOCKS]; unsigned int arrived; unsigned int pad; };
+__global__ void __launch_bounds__(1024) ppo_adv_moments_kernel(const float* ret, const float* val, const int32_t* idx, int n, double* mom, AdvWs* ws) {
   __shared__ double s1[16], s2[16];
   __shared__ int last;
   double a = 0, b = 0;
-  const int base = blockIdx.x * 4096;
-  {
+  for (int base = blockIdx.x * 4096; base < n; base += gridDim.x * 4096) {
     int r[4];
     float x[4], y[4];
 #pragma unroll
@@ -1292,19 +1288,19 @@ __global__ void __launch_bounds__(1024) ppo_adv_moments_kernel(const float* ret,
   if (threadIdx.x == 0) {
     double ta = 0, tb = 0;
     for (int i = 0; i < 16; i++) { ta += s1[i]; tb += s2[i]; }
-    __hip_atomic_store(&g_adv_part[2 * blockIdx.x], ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // sc1: visible to every XCD
-    __hip_atomic_store(&g_adv_part[2 * blockIdx.x + 1], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ws->part[2 * blockIdx.x], ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // sc1: visible to every XCD
+    __hip_atomic_store(&ws->part[2 * blockIdx.x + 1], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int arrived = __hip_atomic_fetch_add(&g_adv_arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int arrived = __hip_atomic_fetch_add(&ws->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = (arrived == gridDim.x - 1);
     if (last) {
       double sa = 0, sb = 0;
       for (unsigned int i = 0; i < gridDim.x; i++) {
-        sa += __hip_atomic_load(&g_adv_part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sb += __hip_atomic_load(&g_adv_part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sa += __hip_atomic_load(&ws->part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sb += __hip_atomic_load(&ws->part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       mom[0] = sa; mom[1] = sb; mom[2] = (double)n;
-      __hip_atomic_store(&g_adv_arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // ready for the next launch
+      __hip_atomic_store(&ws->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // ready for the next call
     }
   }
 }
@@ -1317,13 +1313,26 @@ __global__ void ppo_adv_normalize_kernel(const float* ret, const float* val, con
   int r = idx ? idx[k] : k;
   out[k] = ((ret[r] - val[r]) - m32) / (s32 + 1e-8f);
 }
-extern "C" int ppo_adv_moments(const float* returns, const float* values, const int32_t* idx, int n, double* moments, void* stream) {
-  if (!returns || !values || !moments || n <= 0) FAIL(-1, "bad arguments");
-  const int nb = (n + 4095) / 4096;
-  if (nb > ADV_MAX_BLOCKS) FAIL(-2, "minibatch of %d rows exceeds %d", n, ADV_MAX_BLOCKS * 4096);
-  hipLaunchKernelGGL(ppo_adv_moments_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, returns, values, idx, n, moments);
+extern "C" size_t ppo_adv_moments_workspace_bytes(void) { return sizeof(AdvWs); }
+extern "C" int ppo_adv_moments_ws(const float* returns, const float* values, const int32_t* idx, int n, double* moments, void* workspace,
+                                  void* stream) {
+  if (!returns || !values || !moments || !workspace || n <= 0) FAIL(-1, "bad arguments");
+  int nb = (n + 4095) / 4096;
+  if (nb > ADV_MAX_BLOCKS) nb = ADV_MAX_BLOCKS;     // larger minibatches: the blocks stride over the chunks
+  hipLaunchKernelGGL(ppo_adv_moments_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, returns, values, idx, n, moments, (AdvWs*)workspace);
   HIPCHK(hipGetLastError());
   return 0;
+}
+// convenience form without a caller workspace: library-owned workspaces handed out round robin (16 of them), so calls in flight on
+// different streams do not meet unless more than 16 overlap; a caller that steps several models concurrently passes its own (…_ws)
+extern "C" int ppo_adv_moments(const float* returns, const float* values, const int32_t* idx, int n, double* moments, void* stream) {
+  static AdvWs* pool = nullptr;
+  static unsigned int next = 0;
+  if (!pool) {
+    HIPCHK(hipMalloc((void**)&pool, 16 * sizeof(AdvWs)));
+    HIPCHK(hipMemset(pool, 0, 16 * sizeof(AdvWs)));
+  }
+  return ppo_adv_moments_ws(returns, values, idx, n, moments, pool + (next++ & 15), stream);
 }
 extern "C" int ppo_adv_normalize(const float* returns, const float* values, const int32_t* idx, int n, const double* moments,
                                  float* adv_out, void* stream) {

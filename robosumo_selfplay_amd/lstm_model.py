@@ -67,6 +67,7 @@ class LstmPPOModel(object):
             self.wgrad_native = os.environ.get("SUMO_LSTM_WGRAD", "native") != "blas"
             self.seq_kernels = os.environ.get("SUMO_LSTM_SEQ", "1") != "0"    # whole-sequence forward / BPTT launches (nlstm 128)
             self.xproj = os.environ.get("SUMO_LSTM_XPROJ", "1") != "0"      # input block of the training forward hoisted out of the recurrence
+            self.adv_ws = torch.zeros(ppo_capi.lib().ppo_adv_moments_workspace_bytes(), dtype=torch.uint8, device=self.device)
             self.wg_workspace = torch.empty(ppo_capi.lib().ppo_lstm_wgrad_workspace_bytes(D, H, A), dtype=torch.uint8, device=self.device)
 
     class _X:
@@ -242,7 +243,7 @@ class LstmPPOModel(object):
         nrow = ret.numel()
         st = t.cuda.current_stream(self.device).cuda_stream
         adv = t.empty(nrow, dtype=t.float32, device=self.device)
-        ppo_capi.chk(L.ppo_adv_moments(ret.data_ptr(), val.data_ptr(), None, nrow, self.moments.data_ptr(), st))
+        ppo_capi.chk(L.ppo_adv_moments_ws(ret.data_ptr(), val.data_ptr(), None, nrow, self.moments.data_ptr(), self.adv_ws.data_ptr(), st))
         sdist.allreduce_moments(self.moments, self.comm)                                # global advantage normalisation
         ppo_capi.chk(L.ppo_adv_normalize(ret.data_ptr(), val.data_ptr(), None, nrow, self.moments.data_ptr(), adv.data_ptr(), st))
         self.loss_and_grads(cliprange, obs, ret, masks, actions, adv, neglogpacs, IS_weight, states, T, world=world)

@@ -43,6 +43,7 @@ class PPOModel(object):
             self.stats = torch.zeros(ppo_capi.NSTATS, dtype=torch.float64, device=self.device)
             self.moments = torch.zeros(3, dtype=torch.float64, device=self.device)
             self.workspace = torch.zeros(ppo_capi.lib().ppo_grad_workspace_bytes(D, A), dtype=torch.uint8, device=self.device)   # zeroed once: sumo_ppo.h
+            self.adv_ws = torch.zeros(ppo_capi.lib().ppo_adv_moments_workspace_bytes(), dtype=torch.uint8, device=self.device)   # this model's own (sumo_ppo.h)
             self._graphs = {}
             self._static = None
             self._epoch_moments = None
@@ -107,7 +108,7 @@ class PPOModel(object):
         ip = idx.data_ptr()
         if mom is None:
             mom = self.moments
-            ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, mom.data_ptr(), st))
+            ppo_capi.chk(L.ppo_adv_moments_ws(returns.data_ptr(), values.data_ptr(), ip, n, mom.data_ptr(), self.adv_ws.data_ptr(), st))
             count = float(n)
         else:
             count = float(n) * self._t.distributed.get_world_size(self.comm)       # equal shards: no host read-back of the reduced count
@@ -150,7 +151,7 @@ class PPOModel(object):
         L = ppo_capi.lib()
         for k in range(nmb):
             mb = inds[k * nbatch_train:(k + 1) * nbatch_train]
-            ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), mb.data_ptr(), int(mb.numel()), mom[k].data_ptr(), st))
+            ppo_capi.chk(L.ppo_adv_moments_ws(returns.data_ptr(), values.data_ptr(), mb.data_ptr(), int(mb.numel()), mom[k].data_ptr(), self.adv_ws.data_ptr(), st))
         sdist.allreduce_moments(mom, self.comm)
         self._epoch_moments = mom
         return mom
@@ -285,7 +286,7 @@ class PPOModel(object):
         if mom_k is not None:          # the epoch's moments were all-reduced in one collective (prepare_epoch): nothing to exchange here
             self.moments.copy_(mom_k)
         else:
-            ppo_capi.chk(L.ppo_adv_moments(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), st))
+            ppo_capi.chk(L.ppo_adv_moments_ws(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), self.adv_ws.data_ptr(), st))
             sdist.allreduce_moments(self.moments, self.comm)
         adv = t.empty(n, dtype=t.float32, device=self.device)
         ppo_capi.chk(L.ppo_adv_normalize(returns.data_ptr(), values.data_ptr(), ip, n, self.moments.data_ptr(), adv.data_ptr(), st))

@@ -9,7 +9,7 @@ FWD_PI, FWD_VF, FWD_TANH = 1, 2, 4
 LSTM_GATES_IFOU, LSTM_GATES_IJFO = 0, 1
 _LIB = None
 
-EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_forward_filtered", "ppo_lstm_step", "ppo_lstm_step_pool", "ppo_lstm_step_save", "ppo_lstm_xproj", "ppo_lstm_step_save_z", "ppo_lstm_seq_forward", "ppo_lstm_seq_backward", "ppo_lstm_head_grad", "ppo_lstm_bwd_step", "ppo_lstm_wgrad_workspace_bytes", "ppo_lstm_wgrad", "ppo_selfplay_forward", "ppo_post_step", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments",
+EXPORTS = ("ppo_last_error", "ppo_param_count", "ppo_forward", "ppo_forward_filtered", "ppo_lstm_step", "ppo_lstm_step_pool", "ppo_lstm_step_save", "ppo_lstm_xproj", "ppo_lstm_step_save_z", "ppo_lstm_seq_forward", "ppo_lstm_seq_backward", "ppo_lstm_head_grad", "ppo_lstm_bwd_step", "ppo_lstm_wgrad_workspace_bytes", "ppo_lstm_wgrad", "ppo_selfplay_forward", "ppo_post_step", "ppo_reward_mix", "ppo_vtrace", "ppo_adv_moments", "ppo_adv_moments_ws", "ppo_adv_moments_workspace_bytes",
            "ppo_adv_normalize", "ppo_grad_workspace_bytes", "ppo_grad", "ppo_loss_stats", "ppo_clip_adam")
 
 
@@ -54,6 +54,9 @@ def lib():
         L.ppo_post_step.argtypes = [vp, i32, f64, vp, i32, vp, vp, vp, vp, vp, vp, vp]
         L.ppo_vtrace.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, vp, vp, vp, vp, vp]
         L.ppo_adv_moments.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.ppo_adv_moments_ws.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+        L.ppo_adv_moments_workspace_bytes.argtypes = []
+        L.ppo_adv_moments_workspace_bytes.restype = C.c_size_t
         L.ppo_adv_normalize.argtypes = [vp, vp, vp, i32, vp, vp, vp]
         L.ppo_grad_workspace_bytes.argtypes = [i32, i32]
         L.ppo_grad_workspace_bytes.restype = C.c_size_t
@@ -61,7 +64,7 @@ def lib():
         L.ppo_loss_stats.argtypes = [vp, vp, i32, vp, vp]
         L.ppo_clip_adam.argtypes = [vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, f64, vp, vp]
         for n in EXPORTS:
-            if n not in ("ppo_last_error", "ppo_grad_workspace_bytes", "ppo_lstm_wgrad_workspace_bytes"):
+            if n not in ("ppo_last_error", "ppo_grad_workspace_bytes", "ppo_lstm_wgrad_workspace_bytes", "ppo_adv_moments_workspace_bytes"):
                 getattr(L, n).restype = i32
         _LIB = L
     return _LIB

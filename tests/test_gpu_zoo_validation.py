@@ -29,7 +29,10 @@ _TABLE = {}
 def _record(key, r, rep):
     _TABLE[key] = dict(episodes=r["episodes"], decided=r["decided"], mean_len=r["mean_len"], dist0=r["dist0"], dist_t=r["dist_t"],
                        z_sim=float(r["obs_mean"][2]), samples=r["samples"],
-                       dropped=r["stats"]["dropped"], diverged=r["stats"]["diverged"], max_ncon=r["stats"]["max_ncon"], **rep)
+                       dropped=r["stats"]["dropped"], diverged=r["stats"]["diverged"], max_ncon=r["stats"]["max_ncon"],
+                       # contact-generation fidelity accounting in the play workload (sampled: the forward that opens each env step)
+                       capsule_box_3=r["stats"].get("capsule_box_3"), rod_endcap=r["stats"].get("rod_endcap"),
+                       sampled_forwards=r["stats"]["forward"] / 20.0, **rep)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "zoo_validation.json"), "w") as f:
