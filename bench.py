@@ -43,7 +43,7 @@ F32_MFMA_PEAK_TF = 157.3  # dense f32 matrix-core peak (v_mfma_f32_*_f32), same 
 
 def mfma_probe(torch, dev, learner, opponent, env, obs_b, ret_b, act_b, val_b, nlp_b, nmb_rows, reps=20, use_graph=True):
     """MFMA side of the roofline, measured live with HIP events on the launching stream: `reps` back-to-back calls of ppo_grad on one
-    PPO2 minibatch (forward + backward + weight-gradient MFMAs of both nets; the call also runs the two slab-reduction kernels,
+    PPO2 minibatch (forward + backward + weight-gradient MFMAs of both nets; the call also runs the slab-reduction kernel,
     which are counted in the time but not in the flops) and of ppo_selfplay_forward on one env group (the 5 evaluations of a
     rollout step)."""
     import ctypes as C
@@ -108,7 +108,7 @@ def mfma_probe(torch, dev, learner, opponent, env, obs_b, ret_b, act_b, val_b, n
         tf = flops / (us * 1e-6) / 1e12
         res[name] = {"achieved": tf, "frac": tf / F32_MFMA_PEAK_TF, "us_per_call": us, "flops_per_call": flops,
                      "rows_per_call": n if name == "ppo_grad_kernel" else ng}
-    res["ppo_grad_kernel"]["note"] = "time of the whole ppo_grad call (gradient kernel + two slab-reduction launches); flops of the gradient kernel"
+    res["ppo_grad_kernel"]["note"] = "time of the whole ppo_grad call (gradient kernel + the slab-reduction launch); flops of the gradient kernel"
     return res
 
 

@@ -1371,12 +1371,29 @@ struct GradArgs {
 // waves idle -- and only wave 0 keeps the statistics, the head-bias and the logstd gradients.
 // (round 2's kernel: one wave per tile with the whole gradient of a net in its accumulators, 110 us per 16 384-row minibatch)
 // ---------------------------------------------------------------------------------------------------------
+#ifdef PPO_GRAD_PROBE   /* development build: shader-clock cycles per phase of workgroup (0, policy net), wave 0 (tools/grad_probe.py) */
+__device__ unsigned long long g_gprobe[16];
+#define GP_INIT() unsigned long long gp_t = __builtin_amdgcn_s_memtime(), gp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gp_acc[k] += t_ - gp_t; gp_t = t_; } while (0)
+#define GP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GP_FLUSH() do { if (PI && blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 8; k_++) g_gprobe[k_] = gp_acc[k_]; } while (0)
+#else
+#define GP_INIT() do { } while (0)
+#define GP(k) do { } while (0)
+#define GP_DRAIN() do { } while (0)
+#define GP_FLUSH() do { } while (0)
+#endif
+template <int R>
+__device__ __forceinline__ float quad_bcast(float v) {   // the value of lane R of each quad of lanes, in all four
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), R * 0x55, 0xf, 0xf, false));
+}
 #define GRAD_HS 68   /* activation-tile row stride of the gradient kernel (floats): 16-byte aligned rows, 128-bit reads conflict free */
 template <int KT, bool PI>
 __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int lane, int w) {
   const ParamLayout& L = a.L;
   const int XS = a.XS, D = L.D, A = L.A;
   const int i = lane & 15, kq = lane >> 4, tid = threadIdx.x;
+  GP_INIT();
   constexpr int K0 = 4 * KT;   // k-steps of the first layer (four features per step)
   // Activation tiles: row stride GHS = 68 floats (16-byte aligned rows whose 128-bit reads are bank-conflict free: 68 = 4 mod 32).
   // A-operand convention of this kernel: in k-step u the lane (i, kq) supplies feature kq * (K / 4) + u of row i -- each kq group
@@ -1385,19 +1402,67 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
   constexpr int GHS = GRAD_HS;
   float *xb0 = lds, *xb1 = xb0 + 16 * XS, *h1 = xb1 + 16 * XS, *h2 = h1 + 16 * GHS, *d1 = h2 + 16 * GHS, *d2 = d1 + 16 * GHS;
   float* mydout = d2 + 16 * GHS + w * 16 * 18;   // this wave's copy of the head deltas [16][18]
+  float *rd0 = d2 + 16 * GHS + 4 * 16 * 18, *rd1 = rd0 + 16 * 20;   // per-row loss inputs of the tile (double-buffered like the rows)
+  float4* w2s = (float4*)(rd1 + 16 * 20);   // the head's B operands [4][64 lanes] (the same for every wave): read per tile, 16 registers less
   const Net net = PI ? pi_net(a.params, L) : vf_net(a.params, L);
   const int cw = 16 * w + i;   // the hidden unit this lane's column stands for
   const bool col = i < net.nout;
+  const int ntiles = (a.n + 15) / 16;
+  // ---- observation rows: thread (row = tid / 16, c = tid % 16 + 16 j) -- 16 threads read a row in 64-byte pieces.  The same 16
+  // threads fetch what the loss needs of that row (the action, old neglogp / return, advantage, weight) into a side tile, so that the
+  // head phase reads LDS only: with the gathers (idx -> row -> fields, two dependent trips to HBM at shuffled rows) inside the head
+  // phase it was 55 % of the kernel (tools/grad_probe.py).  The row index itself is fetched one tile further ahead.
+  const int xr = tid >> 4, xc = tid & 15;
+  constexpr int NXJ = KT;   // 16 * KT columns cover D
+  constexpr int RDS = 20;   // side-tile row: actions 0..15 | 16 old neglogp (policy) / return (value) | 17 advantage | 18 weight
+  float xv[NXJ], xact = 0.0f, xsc = 0.0f;
+  auto fetch_src = [&](int tile) -> int {
+    const int row = tile * 16 + xr;
+    return (tile < ntiles && row < a.n) ? (a.idx ? a.idx[row] : row) : -1;
+  };
+  // (request issues plain unconditional loads -- clamped addresses, no select on the loaded value -- so that nothing waits for them
+  // before commit, which applies the masks: a select right behind each load made the compiler predicate the loads pairwise with a wait
+  // after every pair, four serial trips to memory inside the head phase)
+  bool xrok = false;
+  auto request = [&](int tile, int src_) {
+    xrok = src_ >= 0;
+    const int src = xrok ? src_ : 0, row = xrok ? tile * 16 + xr : 0;
+    const float* orow = a.obs + (size_t)src * a.obs_stride;
+#pragma unroll
+    for (int j = 0; j < NXJ; j++) { const int c = xc + 16 * j; xv[j] = orow[c < D ? c : D - 1]; }
+    if (PI) {
+      xact = a.actions[(size_t)src * A + (xc < A ? xc : 0)];
+      const float* sp = xc == 0 ? a.oldnlp + src : (xc == 1 ? a.adv + row : a.weight + src);
+      xsc = sp[0];
+    } else {
+      xsc = a.returns[src];
+    }
+  };
+  auto commit = [&](float* xb, float* rd) {   // columns D .. 16 KT - 1 are written as zeros (the launch sizes the row stride for the variant: XS >= 16 KT)
+#pragma unroll
+    for (int j = 0; j < NXJ; j++) xb[xr * XS + xc + 16 * j] = (xrok && xc + 16 * j < D) ? xv[j] : 0.0f;
+    if (PI) rd[xr * RDS + xc] = xact;
+    if (xc < 3) rd[xr * RDS + 16 + xc] = xrok ? xsc : 0.0f;
+  };
+  int tile = blockIdx.x;
+  request(tile, fetch_src(tile));   // (in flight while the resident operands load)
   // ---- resident B operands (lane (i, kq) holds B[k = kq * (K / 4) + u][column i] of k-step u; the head-delta products keep 4u + kq)
-  float bW0[K0], bW1[16], bW1T[16], bW2[16], bW2T[4];
+  float bW0[K0], bW1[16], bW1T[16], bW2T[4];
 #pragma unroll
   for (int u = 0; u < K0; u++) { const int k = kq * K0 + u; const float v = net.w0[(k < D ? k : D - 1) * H + cw]; bW0[u] = k < D ? v : 0.0f; }
 #pragma unroll
   for (int u = 0; u < 16; u++) {
     bW1[u] = net.w1[(kq * 16 + u) * H + cw];
     bW1T[u] = net.w1[cw * H + kq * 16 + u];                                  // (delta W1^T)[row][f] = sum_k delta[row][k] W1[f][k]
-    const float v = net.w2[(kq * 16 + u) * net.nout + (col ? i : 0)];
-    bW2[u] = col ? v : 0.0f;
+  }
+  if (w == 0) {
+#pragma unroll
+    for (int v4 = 0; v4 < 4; v4++) {
+      float t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const float v = net.w2[(kq * 16 + 4 * v4 + u) * net.nout + (col ? i : 0)]; t[u] = col ? v : 0.0f; }
+      w2s[v4 * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+    }
   }
 #pragma unroll
   for (int u = 0; u < 4; u++) { const int k = 4 * u + kq; const float v = net.w2[cw * net.nout + (k < net.nout ? k : 0)]; bW2T[u] = k < net.nout ? v : 0.0f; }
@@ -1411,31 +1476,15 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
   float gb0 = 0, gb1 = 0, gb2 = 0, glogstd = 0;
   double st_pg = 0, st_vf = 0, st_kl = 0, st_clip = 0, st_cnt = 0;
   const float logstd = (PI && col) ? a.params[L.logstd + i] : 0.0f;
-  const float std = expf(logstd);
+  const float inv_std = 1.0f / expf(logstd);
   const float sum_logstd = row16_sum(logstd);
-  const int ntiles = (a.n + 15) / 16;
-  // ---- observation rows: thread (row = tid / 16, c = tid % 16 + 16 j) -- 16 threads read a row in 64-byte pieces
-  const int xr = tid >> 4, xc = tid & 15;
-  constexpr int NXJ = KT;   // 16 * KT columns cover D
-  float xv[NXJ];
-  auto request = [&](int tile) {
-    const int row = tile * 16 + xr;
-    const bool rok = tile < ntiles && row < a.n;
-    const int src = rok ? (a.idx ? a.idx[row] : row) : 0;
-    const float* orow = a.obs + (size_t)src * a.obs_stride;
-#pragma unroll
-    for (int j = 0; j < NXJ; j++) { const int c = xc + 16 * j; const float v = orow[c < D ? c : D - 1]; xv[j] = (rok && c < D) ? v : 0.0f; }
-  };
-  auto commit = [&](float* xb) {   // columns D .. 16 KT - 1 are written as zeros (the launch sizes the row stride for the variant: XS >= 16 KT)
-#pragma unroll
-    for (int j = 0; j < NXJ; j++) xb[xr * XS + xc + 16 * j] = xv[j];
-  };
-  int tile = blockIdx.x;
-  request(tile);
-  commit(xb0);
+  commit(xb0, rd0);
+  int src_next = fetch_src(tile + gridDim.x);
   __syncthreads();
+  GP(0);   // resident operands + first tile
   for (int it = 0; tile < ntiles; tile += gridDim.x, it++) {
     float* xbuf = (it & 1) ? xb1 : xb0;
+    const float* rd = (it & 1) ? rd1 : rd0;
     const int r0 = tile * 16;
     // ---- first layer, this wave's 16 units: two accumulation chains over the even / odd k-steps
     f32x4 acc = (f32x4){0, 0, 0, 0}, acc2 = (f32x4){0, 0, 0, 0};
@@ -1452,6 +1501,7 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
 #pragma unroll
     for (int r = 0; r < 4; r++) { h1v[r] = fmaxf(acc[r] + acc2[r] + bias0, 0.0f); h1[(4 * kq + r) * GHS + cw] = h1v[r]; }
     __syncthreads();
+    GP(1);
     // ---- second layer
     acc = (f32x4){0, 0, 0, 0}; acc2 = (f32x4){0, 0, 0, 0};
     {
@@ -1466,37 +1516,49 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
 #pragma unroll
     for (int r = 0; r < 4; r++) { h2v[r] = fmaxf(acc[r] + acc2[r] + bias1, 0.0f); h2[(4 * kq + r) * GHS + cw] = h2v[r]; }
     __syncthreads();
-    request(tile + gridDim.x);   // the next tile's rows travel during the head and the backward half
+    GP(2);
+    request(tile + gridDim.x, src_next);   // the next tile's rows travel during the head and the backward half
+    src_next = fetch_src(tile + 2 * gridDim.x);
     // ---- head (every wave) + loss deltas (D layout: rows 4kq+r, column i)
     f32x4 out = (f32x4){0, 0, 0, 0};
     {
       const float4* ha = (const float4*)(h2 + i * GHS + kq * 16);
 #pragma unroll
       for (int v = 0; v < 4; v++) {
-        const float4 q = ha[v];
-        out = MFMA(q.x, bW2[4 * v], out); out = MFMA(q.y, bW2[4 * v + 1], out);
-        out = MFMA(q.z, bW2[4 * v + 2], out); out = MFMA(q.w, bW2[4 * v + 3], out);
+        const float4 q = ha[v], b = w2s[v * 64 + lane];
+        out = MFMA(q.x, b.x, out); out = MFMA(q.y, b.y, out);
+        out = MFMA(q.z, b.z, out); out = MFMA(q.w, b.w, out);
       }
     }
+    if (PI) {
+      // The per-ROW part of the loss (neglogp -> ratio -> clip -> d loss / d neglogp, ~100 instructions) is evaluated ONCE per row: lane
+      // (i, kq) takes row 4 kq + (i & 3), so every quad of lanes holds its group's four rows and hands the result to the other
+      // lanes through quad-broadcast DPP moves.  (With every lane walking all four rows this phase was VALU-bound: 38 % of the kernel.)
+      float zr[4], ssm = 0.0f;
+      const int rm = i & 3;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = r0 + 4 * kq + r;
-      const bool rok = row < a.n;
-      const int src = rok ? (a.idx ? a.idx[row] : row) : 0;
-      float dhead = 0.0f;
-      if (PI) {
+      for (int r = 0; r < 4; r++) {
+        const bool rok = r0 + 4 * kq + r < a.n;
         const float m = out[r] + bias2;
-        const float act = (rok && col) ? a.actions[(size_t)src * A + i] : m;
-        float z = (act - m) / std;
+        const float act = (rok && col) ? rd[(4 * kq + r) * RDS + i] : m;
+        float z = (act - m) * inv_std;
         if (!(rok && col)) z = 0.0f;
+        zr[r] = z;
         const float ss = row16_sum(z * z);
-        const float nlp = 0.5f * ss + 0.5f * LOG2PI_F * (float)A + sum_logstd;
-        const float old = rok ? a.oldnlp[src] : nlp;
+        ssm = rm == r ? ss : ssm;
+      }
+      float dnlp_m;
+      {
+        const int row = r0 + 4 * kq + rm;
+        const bool rok = row < a.n;
+        const float* rdr = rd + (4 * kq + rm) * RDS;
+        const float nlp = 0.5f * ssm + 0.5f * LOG2PI_F * (float)A + sum_logstd;
+        const float old = rok ? rdr[16] : nlp;
         const float lr = old - nlp;
         float ratio = expf(lr);
         const bool isnan_ = ratio != ratio;
         if (isnan_) ratio = 2.0f;                                         // model.py:96
-        const float adv = rok ? a.adv[row] : 0.0f, wt = rok ? a.weight[src] : 0.0f;
+        const float adv = rok ? rdr[17] : 0.0f, wt = rok ? rdr[18] : 0.0f;
         const float lo = 1.0f - a.cliprange, hi = 1.0f + a.cliprange;
         const float rc = fminf(fmaxf(ratio, lo), hi);
         const float l1 = -adv * ratio, l2 = -adv * rc;
@@ -1504,27 +1566,40 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
         const bool in_clip = ratio >= lo && ratio <= hi;
         float dratio = wt * a.inv_count * (first ? -adv : (in_clip ? -adv : 0.0f));
         if (isnan_) dratio = 0.0f;
-        const float dnlp = -dratio * ratio;
-        dhead = col ? dnlp * (-(z / std)) : 0.0f;
-        if (rok && col) glogstd += dnlp * (1.0f - z * z) - a.ent_coef * a.inv_count;
-        if (w == 0 && rok && i == 0) {
+        dnlp_m = -dratio * ratio;
+        if (w == 0 && rok && i < 4) {
           st_pg += (double)(wt * fmaxf(l1, l2));
           st_kl += (double)(nlp - old);
           st_clip += (fabsf(ratio - 1.0f) > a.cliprange) ? 1.0 : 0.0;
           st_cnt += 1.0;
           if (a.log_ratio) a.log_ratio[row] = lr;
         }
-      } else {
-        const float v = out[r] + bias2;
-        const float R = rok ? a.returns[src] : v;
-        const float dv = v - R;
-        dhead = (rok && col) ? a.vf_coef * a.inv_count * dv : 0.0f;
-        if (w == 0 && rok && i == 0) { st_vf += 0.5 * (double)dv * (double)dv; st_cnt += 1.0; }
       }
-      mydout[(4 * kq + r) * 18 + i] = dhead;
-      gb2 += dhead;
+      float dn[4];
+      dn[0] = quad_bcast<0>(dnlp_m); dn[1] = quad_bcast<1>(dnlp_m); dn[2] = quad_bcast<2>(dnlp_m); dn[3] = quad_bcast<3>(dnlp_m);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const bool rok = r0 + 4 * kq + r < a.n;
+        const float dhead = col ? dn[r] * (-(zr[r] * inv_std)) : 0.0f;
+        if (rok && col) glogstd += dn[r] * (1.0f - zr[r] * zr[r]) - a.ent_coef * a.inv_count;
+        mydout[(4 * kq + r) * 18 + i] = dhead;
+        gb2 += dhead;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const bool rok = r0 + 4 * kq + r < a.n;
+        const float v = out[r] + bias2;
+        const float R = rok ? rd[(4 * kq + r) * RDS + 16] : v;
+        const float dv = v - R;
+        const float dhead = (rok && col) ? a.vf_coef * a.inv_count * dv : 0.0f;
+        if (w == 0 && rok && i == 0) { st_vf += 0.5 * (double)dv * (double)dv; st_cnt += 1.0; }
+        mydout[(4 * kq + r) * 18 + i] = dhead;
+        gb2 += dhead;
+      }
     }
     wave_sync();
+    GP(3);
     // ---- head weight gradient, rows 16w .. 16w+15: gW2 += h2[:, slice]^T dhead
 #pragma unroll
     for (int s_ = 0; s_ < 4; s_++) { const int row = 4 * s_ + kq; gW2 = MFMA(h2[row * GHS + cw], mydout[row * 18 + i], gW2); }
@@ -1539,6 +1614,7 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
 #pragma unroll
     for (int r = 0; r < 4; r++) { const float d = h2v[r] > 0.0f ? acc[r] : 0.0f; d2[(4 * kq + r) * GHS + cw] = d; gb1 += d; }
     __syncthreads();
+    GP(4);
     // ---- gW1[:, slice] += h1^T d2[:, slice]
 #pragma unroll
     for (int s_ = 0; s_ < 4; s_++) {
@@ -1561,6 +1637,7 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
 #pragma unroll
     for (int r = 0; r < 4; r++) { const float d = h1v[r] > 0.0f ? acc[r] + acc2[r] : 0.0f; d1[(4 * kq + r) * GHS + cw] = d; gb0 += d; }
     wave_sync();
+    GP(5);
     // ---- gW0[:, slice] += x^T d1[:, slice]
 #pragma unroll
     for (int s_ = 0; s_ < 4; s_++) {
@@ -1569,8 +1646,9 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
 #pragma unroll
       for (int ft = 0; ft < KT; ft++) gW0[ft] = MFMA(xbuf[row * XS + ft * 16 + i], b, gW0[ft]);
     }
-    commit((it & 1) ? xb0 : xb1);
+    commit((it & 1) ? xb0 : xb1, (it & 1) ? rd0 : rd1);
     __syncthreads();   // the tile's buffers are free again, the next tile's rows are in place
+    GP(6);
   }
   // ---- this block's partial gradients (slab) -- D layout: rows 4kq+r of the tile, column i
   float* slab = a.slabs + ((size_t)(PI ? 0 : 1) * a.nwaves + blockIdx.x) * L.P;
@@ -1597,8 +1675,13 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
   if (w == 0) {
     const float s2 = kq_sum(gb2), sl = kq_sum(glogstd);
     if (kq == 0 && col) { slab[o_b2 + i] = s2; if (PI) slab[L.logstd + i] = sl; }
-    // stats: lanes with i == 0 hold per-kq partials
+    // stats: the lanes that took rows (policy net: i = 0..3 of each group; value net: i == 0) hold the partials
     double t_pg = st_pg, t_vf = st_vf, t_kl = st_kl, t_clip = st_clip, t_cnt = st_cnt;
+    if (PI) {   // (policy net: the lanes i = 0..3 of a group hold the partials of their rows)
+      for (int o = 1; o < 4; o <<= 1) {
+        t_pg += __shfl_xor(t_pg, o, WAVE); t_kl += __shfl_xor(t_kl, o, WAVE); t_clip += __shfl_xor(t_clip, o, WAVE); t_cnt += __shfl_xor(t_cnt, o, WAVE);
+      }
+    }
     for (int o = 16; o < 64; o <<= 1) {
       t_pg += __shfl_xor(t_pg, o, WAVE); t_vf += __shfl_xor(t_vf, o, WAVE); t_kl += __shfl_xor(t_kl, o, WAVE);
       t_clip += __shfl_xor(t_clip, o, WAVE); t_cnt += __shfl_xor(t_cnt, o, WAVE);
@@ -1608,9 +1691,12 @@ __device__ __forceinline__ void grad_net_coop(const GradArgs& a, float* lds, int
       ws[0] = t_pg; ws[1] = t_vf; ws[2] = 0; ws[3] = t_kl; ws[4] = t_clip; ws[5] = 0; ws[6] = PI ? t_cnt : 0.0; ws[7] = 0;
     }
   }
+  GP_DRAIN();
+  GP(7);   // slab
+  GP_FLUSH();
 }
 
-#define GRAD_LDS_FLOATS(XS) (2 * 16 * (XS) + 4 * 16 * GRAD_HS + 4 * 16 * 18)
+#define GRAD_LDS_FLOATS(XS) (2 * 16 * (XS) + 4 * 16 * GRAD_HS + 4 * 16 * 18 + 2 * 16 * 20 + 4 * 64 * 4)
 // Ant (KT = 8): 255 registers, two workgroups per CU.  The wider first layers of the Bug / Spider nets (KT = 11 / 14: 44 / 56 resident
 // B operands and as many accumulators) get the whole register file of a SIMD instead of spilling: one workgroup per CU.
 template <int KT>
@@ -1628,6 +1714,21 @@ __global__ void __launch_bounds__(256, (KT <= 8 ? 2 : 1)) ppo_grad_kernel(GradAr
 #define RED_GROUP 16
 __global__ void __launch_bounds__(256) ppo_grad_reduce_kernel(const float* slabs, int nslabs, ParamLayout L, float* partial, int G,
                                                               unsigned int* arrived, const double* wstats, float* grads, double* stats) {
+  if (blockIdx.x == gridDim.x - 1) {   // one extra workgroup (column gridDim.x - 1, row 0; the rest of that column leaves): the
+    if (blockIdx.y != 0) return;       // statistics, 8 x 2*nslabs records written by the gradient kernel, i.e. before this launch --
+    __shared__ double chunk[32][8];    // 32 chunks per statistic in parallel, then the chunks in order
+    const int k = threadIdx.x & 7, c = threadIdx.x >> 3, n = 2 * nslabs, per = (n + 31) / 32;
+    double acc = 0;
+    for (int w = c * per; w < (c + 1) * per && w < n; w++) acc += wstats[(size_t)w * 8 + k];
+    chunk[c][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      double t = 0;
+      for (int q = 0; q < 32; q++) t += chunk[q][threadIdx.x];
+      stats[threadIdx.x] += t;
+    }
+    return;
+  }
   const int p = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
   __shared__ int last;
   if (p < L.P) {
@@ -1651,23 +1752,17 @@ __global__ void __launch_bounds__(256) ppo_grad_reduce_kernel(const float* slabs
   }
   __syncthreads();
   if (!last) return;
-  if (p < L.P) {
+  if (p < L.P) {   // the partials in their fixed order, 16 loads in flight at a time (one dependent trip per load was most of this kernel)
     float acc = 0.0f;
-    for (int q = 0; q < G; q++) acc += __hip_atomic_load(partial + (size_t)q * L.P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    grads[p] = acc;
-  }
-  if (blockIdx.x == 0) {   // 8 statistics x 2*nslabs records (written by the gradient kernel, i.e. before this launch): 32 chunks per
-    __shared__ double chunk[32][8];                                         // statistic in parallel, then the chunks in order
-    const int k = threadIdx.x & 7, c = threadIdx.x >> 3, n = 2 * nslabs, per = (n + 31) / 32;
-    double acc = 0;
-    for (int w = c * per; w < (c + 1) * per && w < n; w++) acc += wstats[(size_t)w * 8 + k];
-    chunk[c][k] = acc;
-    __syncthreads();
-    if (threadIdx.x < 8) {
-      double t = 0;
-      for (int q = 0; q < 32; q++) t += chunk[q][threadIdx.x];
-      stats[threadIdx.x] += t;
+    for (int q0 = 0; q0 < G; q0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        v[k] = q0 + k < G ? __hip_atomic_load(partial + (size_t)(q0 + k) * L.P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) acc += v[k];
     }
+    grads[p] = acc;
   }
 }
 
@@ -1727,12 +1822,18 @@ extern "C" int ppo_grad(const float* params, const float* obs, int obs_stride, i
     float* partial = (float*)((char*)workspace + (size_t)2 * grad_nwaves() * a.L.P * sizeof(float) + (size_t)2 * grad_nwaves() * 8 * sizeof(double));
     const int G = (a.nwaves + RED_GROUP - 1) / RED_GROUP;
     unsigned int* arrived = (unsigned int*)(partial + (size_t)(grad_nwaves() / RED_GROUP) * a.L.P);
-    hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3((a.L.P + 255) / 256, G), dim3(256), 0, s, a.slabs, a.nwaves, a.L, partial, G, arrived,
+    hipLaunchKernelGGL(ppo_grad_reduce_kernel, dim3((a.L.P + 255) / 256 + 1, G), dim3(256), 0, s, a.slabs, a.nwaves, a.L, partial, G, arrived,
                        a.wstats, grads, stats);
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
+
+#ifdef PPO_GRAD_PROBE
+extern "C" int ppo_debug_gprobe(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gprobe), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // clip_by_global_norm + TF1 Adam.  Every block computes the global norm itself (same loads, same order -> the same
