@@ -1295,9 +1295,17 @@ __global__ void __launch_bounds__(1024) ppo_adv_moments_kernel(const float* ret,
     last = (arrived == gridDim.x - 1);
     if (last) {
       double sa = 0, sb = 0;
-      for (unsigned int i = 0; i < gridDim.x; i++) {
-        sa += __hip_atomic_load(&ws->part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sb += __hip_atomic_load(&ws->part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned int i0 = 0; i0 < gridDim.x; i0 += 8) {   // eight pairs in flight at a time, summed in their fixed order
+        double va[8], vb[8];
+#pragma unroll
+        for (unsigned int k = 0; k < 8; k++) {
+          const unsigned int i = i0 + k < gridDim.x ? i0 + k : i0;
+          va[k] = __hip_atomic_load(&ws->part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          vb[k] = __hip_atomic_load(&ws->part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (unsigned int k = 0; k < 8; k++)
+          if (i0 + k < gridDim.x) { sa += va[k]; sb += vb[k]; }
       }
       mom[0] = sa; mom[1] = sb; mom[2] = (double)n;
       __hip_atomic_store(&ws->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // ready for the next call
