@@ -530,8 +530,12 @@ __device__ __forceinline__ T load_rec(const T* p) {
 // ---- position / velocity stage --------------------------------------------------------------------------
 #define BYTE_OF(word64, p) ((int)(((word64) >> (8 * (p))) & 0xFFull))
 
+// One body's frame from its parent's (mj_kinematics, one tree level per call; lane == body id).  Only what the CHILDREN wait for is
+// computed here: the joint's own rotation `ql` (a sin / cos pair that depends on qpos alone) comes from a pass over all bodies before
+// the level loop, and the inertial-frame outputs (xipos, gaxis) are left to kin_inertial_frames after it -- the same operations on the
+// same operands, but once on all body lanes instead of once per level on 2 - 8 of them.
 template <class C>
-__device__ __forceinline__ void kin_own_body(C& c) {  // lane == body id
+__device__ __forceinline__ void kin_own_body(C& c, const double (&ql)[4]) {
   KCONSTS();
   const int b = c.lane, pid = K.b_parent;
   double* qpos = S(qpos);
@@ -551,13 +555,12 @@ __device__ __forceinline__ void kin_own_body(C& c) {  // lane == body id
     mulquat(xq, S(xquat) + 4 * pid, K.b_quat);
     if (K.b_jnt >= 0) {
       const int j = K.b_jnt;
-      double ql[4], anchor[3];
+      double anchor[3];
       quat2mat(R, xq);
       mulmatvec3(v, R, K.j_pos);
       for (int k = 0; k < 3; k++) { anchor[k] = xp[k] + v[k]; S(xanchor)[3 * j + k] = anchor[k]; }
       mulmatvec3(v, R, K.j_axis);
       for (int k = 0; k < 3; k++) S(xaxis)[3 * j + k] = v[k];
-      axisangle2quat(ql, K.j_axis, qpos[K.b_qadr] - K.j_qpos0);
       mulquat(xq, xq, ql);
       quat2mat(R, xq);
       mulmatvec3(v, R, K.j_pos);
@@ -567,10 +570,23 @@ __device__ __forceinline__ void kin_own_body(C& c) {  // lane == body id
   }
   for (int k = 0; k < 3; k++) S(xpos)[3 * b + k] = xp[k];
   for (int k = 0; k < 4; k++) S(xquat)[4 * b + k] = xq[k];
+}
+template <class C>
+__device__ __forceinline__ void kin_joint_rotation(C& c, double (&ql)[4]) {   // every body lane at once, before the level loop
+  KCONSTS();
+  ql[0] = 1.0; ql[1] = ql[2] = ql[3] = 0.0;
+  if (c.lane >= 1 && c.lane < c.P->mdl.nbody && !K.b_isfree && K.b_jnt >= 0) axisangle2quat(ql, K.j_axis, S(qpos)[K.b_qadr] - K.j_qpos0);
+}
+template <class C>
+__device__ __forceinline__ void kin_inertial_frames(C& c) {   // every body lane at once, after the level loop (reads its own frame back)
+  KCONSTS();
+  const int b = c.lane;
+  double xp[3], xq[4], R[9], v[3], qi[4];
+  for (int k = 0; k < 3; k++) xp[k] = S(xpos)[3 * b + k];
+  for (int k = 0; k < 4; k++) xq[k] = S(xquat)[4 * b + k];
   quat2mat(R, xq);
   mulmatvec3(v, R, K.b_ipos);
   for (int k = 0; k < 3; k++) S(xipos)[3 * b + k] = xp[k] + v[k];
-  double qi[4];
   mulquat(qi, xq, K.b_iquat);
   quat2mat(R, qi);
   S(gaxis)[3 * b] = R[2]; S(gaxis)[3 * b + 1] = R[5]; S(gaxis)[3 * b + 2] = R[8];
@@ -628,10 +644,14 @@ __device__ __forceinline__ void position_velocity(C& c) {
   PROF(0);
   {
     const int my_level = pt_global(launder_ptr(c.kp))->b_level;
+    double ql[4];
+    kin_joint_rotation(c, ql);
     for (int lvl = 1; lvl < aux.ndepth; lvl++) {
-      if (my_level == lvl) kin_own_body(c);
+      if (my_level == lvl) kin_own_body(c, ql);
       SYNC();
     }
+    if (my_level >= 1 && my_level < aux.ndepth) kin_inertial_frames(c);
+    SYNC();
   }
   PROF(1);
   // subtree CoM of each agent's root
