@@ -3266,7 +3266,7 @@ static int build_aux(sumo_engine* E, std::vector<int>& ai, std::vector<double>& 
   return 0;
 }
 
-static void build_layout(sumo_engine* E) {
+static void build_layout_with(sumo_engine* E, int jb_extra) {
   const sumo_model_t* m = &E->hm;
   Layout& L = E->L;
   int nq = m->nq, nv = m->nv, nb = m->nbody, nj = m->njnt, nu = m->nu;
@@ -3332,6 +3332,7 @@ static void build_layout(sumo_engine* E) {
     int need = 7 * nb + 6 * nj;
     L.jbcap = L.maxcon;
     if ((need - 16) / 24 > L.jbcap) L.jbcap = (need - 16) / 24;
+    L.jbcap += jb_extra;
     { const char* jc = getenv("SUMO_JBCAP"); if (jc && atoi(jc) > 0) L.jbcap = atoi(jc); }
     int jb0 = o, jbsz = 24 * L.jbcap + 16;
     L.Jb = take(jbsz > need ? jbsz : need);
@@ -3354,6 +3355,20 @@ static void build_layout(sumo_engine* E) {
   L.stat_i = itake(SUMO_STAT_LDS ? E->aux.n_stat_i : 0);
   L.b_dofidx = io * 4;
   L.total_bytes = o * 8 + io * 4 + 16 * L.maxcon;
+}
+// The LDS a wave slot leaves unused at the scene's residency (160 KB / waves per CU - the env record) goes to the contact-Jacobian
+// pool: a contact between two moving bodies takes two halves, and wrestling Spiders overflowed a pool of `maxcon` halves about twice
+// per million env steps (counted in `dropped`).  Ant-vs-Ant has 32 B to spare (8 x 20 448 B = 163 584 of 163 840): unchanged.
+static void build_layout(sumo_engine* E) {
+  build_layout_with(E, 0);
+  const int lds_cu = 160 * 1024, slots = lds_cu / E->L.total_bytes;
+  if (slots < 1 || getenv("SUMO_JBCAP")) return;
+  const int budget = lds_cu / slots / 1280 * 1280;   // LDS is allocated in granules of 1280 B on gfx950
+  int extra = (budget - E->L.total_bytes) / (24 * 8);
+  if (extra > E->L.maxcon) extra = E->L.maxcon;      // (a pool of 2 x maxcon halves can never overflow)
+  if (extra <= 0) return;
+  build_layout_with(E, extra);
+  if (lds_cu / E->L.total_bytes != slots) build_layout_with(E, 0);   // (cannot happen: the growth was sized to fit)
 }
 
 static int model_ints(const sumo_model_t* m, int32_t* out);
