@@ -44,8 +44,27 @@ def build_all(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            _codegen_check(tpath)
         out.append(tpath)
     return out
+
+
+def _codegen_check(lib):
+    """After every (re)build: the static check for partial-EXEC save copies (codegen_check.py).  A hit does not stop the build -- the
+    library is still the product and tests/test_codegen_check.py reports it -- unless SUMO_CODEGEN_CHECK=strict."""
+    import sys
+    try:
+        from . import codegen_check
+        hits = codegen_check.scan_library(lib)
+    except Exception as e:                       # objcopy / llvm-objdump missing: the check is a development aid, not a build step
+        print("codegen check skipped for %s: %r" % (os.path.basename(lib), e), file=sys.stderr)
+        return
+    if hits:
+        msg = "%s: partial-EXEC save copies in %s (robosumo_selfplay_amd/codegen_check.py; perturb the source near them and rebuild)" % (
+            os.path.basename(lib), ", ".join("%s x%d" % (k[:60], len(v)) for k, v in hits.items()))
+        if os.environ.get("SUMO_CODEGEN_CHECK") == "strict":
+            raise RuntimeError(msg)
+        print("WARNING: " + msg, file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,125 @@
+"""Static check of a built HIP library for a code-generation hazard of this toolchain found in round 3 ("partial-EXEC
+save copies"): the register allocator parks a long-lived VGPR in a spare register with a `v_mov_b32 vA, vB` (or re-materialises a constant
+into vA) and places that copy at the top of a join block BEFORE the `s_or_b64 exec, exec, ...` that re-activates the lanes -- i.e. inside
+the predicated region `s_and_saveexec_b64 ... s_or_b64 exec`.  The copy then happens only in the lanes the region left active; the later
+restore `v_mov_b32 vB, vA` runs with all lanes active and hands the other lanes whatever vA held before: the previous wave's leftovers.
+Observed in the Ant kernels (256-register budget): lanes >= nv got stale LDS addresses / offsets from the second forward-dynamics call on,
+a few env steps per 10^4 diverged, run-to-run nondeterministically (tools/determinism_diag.py; tools/scrub_bisect.py located the register).
+
+The signature looked for: inside a branch-free predicated region, a plain VGPR move whose destination (a) is not consumed inside the region,
+(b) has NO other write in the whole kernel (a conditional assignment `if (c) x = v` always has one: x's earlier value) and (c) is read
+somewhere.  `scan_library` lists such copies per kernel; the build warns about them and tests/test_codegen_check.py fails on them."""
+import os
+import re
+import subprocess
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+def disassemble(lib):
+    d = tempfile.mkdtemp()
+    fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co], text=True)
+
+
+def vregs(tok):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def kernels(asm):
+    cur, body = None, []
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            if cur:
+                yield cur, body
+            cur, body = m.group(1), []
+            continue
+        if cur:
+            t = line.split("//")[0].strip()
+            if t:
+                body.append(t)
+    if cur:
+        yield cur, body
+
+
+def check(body):
+    """-> list of (index, text) of suspicious copies."""
+    bad = []
+    i, n = 0, len(body)
+    while i < n:
+        m = re.match(r"s_and_saveexec_b64 (s\[\d+:\d+\]), ", body[i])
+        if not m:
+            i += 1
+            continue
+        save = m.group(1)
+        j, ok = i + 1, False
+        while j < n and j < i + 200:
+            t = body[j]
+            if t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")) or re.match(r"s_and_saveexec_b64|s_or_saveexec_b64", t):
+                break
+            if t.startswith("s_or_b64 exec, exec, " + save):
+                ok = True
+                break
+            j += 1
+        if ok:      # straight-line predicated region body[i+1 : j]
+            region = body[i + 1:j]
+            for k, t in enumerate(region):
+                mm = re.match(r"v_mov_b32_e32 v(\d+), (.+)$", t) or re.match(r"v_mov_b64_e32 v\[(\d+):\d+\], (.+)$", t)
+                if not mm:
+                    continue
+                dst = int(mm.group(1))
+                used = any(dst in vregs(u.split(None, 1)[1] if " " in u else "") and not re.match(r"v_mov_b(32|64)_e32 v\[?%d\b" % dst, u)
+                           for u in region[k + 1:])
+                # a copy whose destination is an operand of a later instruction of the region (e.g. the address of its load) belongs there
+                if not used:
+                    bad.append((i + 1 + k, t))
+            i = j + 1
+        else:
+            i += 1
+    return bad
+
+
+
+def scan_kernel(body):
+    """-> [(instruction index, text, reads)] of suspicious copies in one kernel's instruction list."""
+    out = []
+    for idx, t in check(body):
+        dst = int(re.search(r"v\[?(\d+)", t).group(1))
+        writes = reads = 0
+        for u in body:
+            if " " not in u:
+                continue
+            op, rest = u.split(None, 1)
+            ops = rest.split(",")
+            stores = op.startswith(("ds_write", "global_store", "scratch_store", "flat_store", "buffer_store", "global_atomic", "ds_add"))
+            if not stores and not op.startswith(("s_", "v_cmp", "v_cmpx")) and dst in vregs(ops[0]):
+                writes += 1
+                if len(ops) > 1 and dst in vregs(",".join(ops[1:])):
+                    reads += 1
+            elif dst in vregs(rest):
+                reads += 1
+        if writes == 1 and reads >= 1:
+            out.append((idx, t, reads))
+    return out
+
+
+def scan_library(lib, name_filters=()):
+    """-> {kernel name: [(index, text, reads)]} for the kernels of `lib` (a .so with an embedded gfx950 code object) that hold suspicious copies."""
+    hits = {}
+    for name, body in kernels(disassemble(lib)):
+        if name_filters and not any(s in name for s in name_filters):
+            continue
+        h = scan_kernel(body)
+        if h:
+            hits[name] = h
+    return hits

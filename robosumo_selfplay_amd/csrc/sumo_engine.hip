@@ -1650,7 +1650,11 @@ __device__ __forceinline__ void newton_solve(C& c) {
   int iters = 0;
   // loop invariants of this lane's dof, kept in registers: its limit rows, smooth force and unconstrained acceleration
   const LimRows lq = lim_rows(c);
-  const double qsm_i = lane < nv ? S(qsm)[lane] : 0.0, asmo_i = lane < nv ? S(asmo)[lane] : 0.0;
+  // (unconditional loads at a clamped index + selects: no predicated region right in front of the iteration loop -- the register
+  // allocator parked loop-invariant registers of the step loop in exactly such a region once, see tools/exec_copy_check.py)
+  double qsm_i = S(qsm)[lane < nv ? lane : 0], asmo_i = S(asmo)[lane < nv ? lane : 0];
+  asm volatile("" : "+v"(qsm_i), "+v"(asmo_i));
+  qsm_i = lane < nv ? qsm_i : 0.0; asmo_i = lane < nv ? asmo_i : 0.0;
   PROF(11);
   for (int iter = 0; iter < maxiter; iter++) {
     iters++;
@@ -2224,7 +2228,24 @@ extern __shared__ double smem_dyn[];
 // wrote shows up as NaN in the parity tests instead of depending on what the previous step / workgroup left there
 __device__ __forceinline__ void poison_lds(const Params* P, int lane) {
   const int n = P->L.total_bytes / 8;
-  for (int i = lane; i < n; i += WAVE) smem_dyn[i] = (SUMO_DBG_POISON_LDS == 2 ? __longlong_as_double(0x7FF8DEADBEEF0000ll) : (SUMO_DBG_POISON_LDS == 1 ? 1e300 : 0.0));
+#ifndef SUMO_DBG_POISON_LO
+#define SUMO_DBG_POISON_LO 0
+#define SUMO_DBG_POISON_HI 0x7fffffff
+#endif
+  // kinds 4 / 5: PLAUSIBLE leftovers -- what another env's step would leave in the slot: doubles of order one (kind 4) or pairs of
+  // small integers (kind 5), different in every word and workgroup (uniform patterns hide reads that are compared or used as masks);
+  // LO / HI restrict the fill to a range of 8-byte words (bisection)
+  for (int i = lane; i < n; i += WAVE) {
+    if (i < SUMO_DBG_POISON_LO || i >= SUMO_DBG_POISON_HI) continue;
+    unsigned h = (unsigned)i * 2654435761u + (unsigned)blockIdx.x * 40503u + 12345u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    double v = 0.0;
+    if (SUMO_DBG_POISON_LDS == 1) v = 1e300;
+    else if (SUMO_DBG_POISON_LDS == 2) v = __longlong_as_double(0x7FF8DEADBEEF0000ll);
+    else if (SUMO_DBG_POISON_LDS == 4) v = ((double)(h & 0xFFFFFu) / 524288.0 - 1.0) * 1.5;
+    else if (SUMO_DBG_POISON_LDS == 5) v = __longlong_as_double((long long)(h % 24u) | ((long long)((h >> 8) % 24u) << 32));
+    smem_dyn[i] = v;
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   {   // what ctx_init keeps in LDS for the whole launch: the world geoms' centres / axes
     const int nb = P->mdl.nbody, nw = P->aux.nworld;
@@ -2402,7 +2423,11 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_
   poison_lds(P, lane);
 #endif
 #ifdef SUMO_DBG_DUMP
+#ifdef SUMO_DBG_DUMP_ALL   /* every env dumps: the buffer holds [N][20][8][64] doubles */
+  c.dbg = a.dbg_qacc ? a.dbg_qacc + (size_t)e * (20 * 8 * 64) : nullptr;
+#else
   c.dbg = e == 0 ? a.dbg_qacc : nullptr;
+#endif
 #endif
   env_step_body(c, a, e);
   flush_stats(c, a.stats);
