@@ -52,9 +52,8 @@ def kernels(asm):
         yield cur, body
 
 
-def check(body):
-    """-> list of (index, text) of suspicious copies."""
-    bad = []
+def regions(body):
+    """Yields (first, last) instruction indices of the bodies of branch-free predicated regions `s_and_saveexec_b64 sX, .. ; ... ; s_or_b64 exec, exec, sX`."""
     i, n = 0, len(body)
     while i < n:
         m = re.match(r"s_and_saveexec_b64 (s\[\d+:\d+\]), ", body[i])
@@ -71,23 +70,34 @@ def check(body):
                 ok = True
                 break
             j += 1
-        if ok:      # straight-line predicated region body[i+1 : j]
-            region = body[i + 1:j]
-            for k, t in enumerate(region):
-                mm = re.match(r"v_mov_b32_e32 v(\d+), (.+)$", t) or re.match(r"v_mov_b64_e32 v\[(\d+):\d+\], (.+)$", t)
-                if not mm:
-                    continue
-                dst = int(mm.group(1))
-                used = any(dst in vregs(u.split(None, 1)[1] if " " in u else "") and not re.match(r"v_mov_b(32|64)_e32 v\[?%d\b" % dst, u)
-                           for u in region[k + 1:])
-                # a copy whose destination is an operand of a later instruction of the region (e.g. the address of its load) belongs there
-                if not used:
-                    bad.append((i + 1 + k, t))
+        if ok:
+            yield i + 1, j
             i = j + 1
         else:
             i += 1
+
+
+def check(body):
+    """-> list of (index, text) of register moves inside such a region whose destination the region itself does not consume."""
+    bad = []
+    for a, b in regions(body):
+        region = body[a:b]
+        for k, t in enumerate(region):
+            mm = re.match(r"v_mov_b32_e32 v(\d+), (.+)$", t) or re.match(r"v_mov_b64_e32 v\[(\d+):\d+\], (.+)$", t)
+            if not mm:
+                continue
+            dst = int(mm.group(1))
+            used = any(dst in vregs(u.split(None, 1)[1] if " " in u else "") and not re.match(r"v_mov_b(32|64)_e32 v\[?%d\b" % dst, u)
+                       for u in region[k + 1:])
+            if not used:
+                bad.append((a + k, t))
     return bad
 
+
+def check_spills(body):
+    """-> list of (index, text): VGPR spill stores inside such a region (the same placement through the scratch frame: only the region's
+    lanes reach the slot).  The shipped kernels have none."""
+    return [(k, body[k]) for a, b in regions(body) for k in range(a, b) if body[k].startswith("scratch_store")]
 
 
 def scan_kernel(body):
@@ -110,6 +120,7 @@ def scan_kernel(body):
                 reads += 1
         if writes == 1 and reads >= 1:
             out.append((idx, t, reads))
+    out += [(idx, t, 0) for idx, t in check_spills(body)]
     return out
 
 
