@@ -3298,7 +3298,9 @@ static void build_layout_with(sumo_engine* E, int jb_extra) {
   L.ld = nv | 1;
   int nhinge = 0;
   for (int j = 0; j < nj; j++) if (SUMO_I(m, jnt_type)[j] == SUMO_JNT_HINGE) nhinge++;
-  L.maxcon = nv <= 28 ? 24 : (nv <= 36 ? 32 : 40);
+  // Ant-vs-Ant: 18 contact records (the soaks and the zoo play never saw more than 14) instead of 24: the 1 KB goes to the contact-Jacobian pool
+  // (build_layout: 29 halves instead of 24 -- 14 contacts between two moving bodies fit), which is what overflowed a few times per 10^8 forwards
+  L.maxcon = nv <= 28 ? 18 : (nv <= 36 ? 32 : 40);
   const char* mc = getenv("SUMO_MAXCON");
   if (mc && atoi(mc) > 0) L.maxcon = atoi(mc);
   { int cap = 16 * (nv <= 36 ? 2 : 3); if (L.maxcon > cap) L.maxcon = cap; }  // contact rows per lane held in registers by the line search (newton_solve RPL)
