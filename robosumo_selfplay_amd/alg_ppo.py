@@ -80,8 +80,15 @@ def assemble_update_batch(obs, returns, masks, actions, values, neglogpacs, rewa
 def selection_probs(action_prob, new_action_probs):
     """alg_ppo.py:237-242: mean |new/old - 1| of the candidates' ``action_probability`` outputs on the last rollout's opponent
     samples, normalised to sampling probabilities (uniform when every candidate equals the current opponent)."""
-    rd = np.array([float((nap / action_prob - 1.0).abs().mean().item()) for nap in new_action_probs])
-    return rd / rd.sum() if rd.sum() > 0 else np.full(len(rd), 1.0 / len(rd))
+    import torch
+
+    def score(nap):
+        r = nap / action_prob - 1.0
+        r = r[torch.isfinite(r)]           # a probability that underflowed to 0 in float32 (sharp late-training policies) gives inf / NaN here;
+        return float(r.abs().mean().item()) if r.numel() else 0.0      # the reference would pass NaN to np.random.choice and stop -- those samples are left out
+    rd = np.array([score(nap) for nap in new_action_probs])
+    tot = rd.sum()
+    return rd / tot if np.isfinite(tot) and tot > 0 else np.full(len(rd), 1.0 / len(rd))
 
 
 def learn(*, network, env, total_timesteps, opponent_mode="ours", use_opponent_data=None, eval_env=None, seed=None, nsteps=2048,

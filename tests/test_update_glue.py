@@ -79,6 +79,13 @@ def test_selection_probs_match_oracle():
     # raises; here the draw falls back to uniform (documented deviation)
     u = alg_ppo.selection_probs(torch.from_numpy(ap), [torch.from_numpy(ap)] * 3)
     assert np.allclose(u, 1 / 3)
+    # action probabilities that underflowed to 0 in float32 (sharp policies late in training): inf / NaN ratios are left out of the
+    # mean instead of poisoning the draw (seen after ~390 updates of a soak: "probabilities contain NaN")
+    ap0 = ap.copy(); ap0[:5] = 0.0
+    n0 = [x.copy() for x in naps]; n0[1][:2] = 0.0
+    g0 = alg_ppo.selection_probs(torch.from_numpy(ap0), [torch.from_numpy(x) for x in n0])
+    w0 = po.opponent_selection_probs(ap[5:], [x[5:] for x in naps])
+    assert np.isfinite(g0).all() and abs(g0.sum() - 1) < 1e-12 and np.allclose(g0, w0, rtol=1e-5)
 
 
 def test_minibatch_slices_cover_ragged_batch():
