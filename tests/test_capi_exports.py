@@ -82,3 +82,35 @@ def test_static_layout_header_is_current():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_static_layout.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]
+
+
+def test_layout_fits_the_residency_and_the_pool_takes_the_spare_lds():
+    """build_layout through the host-only export: every scene's env record fits its residency (8 envs per CU for Ant-vs-Ant, 4 for the
+    Spiders: 160 KB in granules of 1280 B), the contact-Jacobian pool holds at least one half per contact record and takes the LDS the
+    residency leaves unused (round 3: Ant 18 records / 29 halves, Spider 40 / 52)."""
+    import ctypes as C
+    import re
+    from robosumo_selfplay_amd import build, mjcf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "robosumo_selfplay_amd", "csrc", "sumo_engine.hip")).read()
+    body = src[src.index("struct Layout {"):]
+    body = re.sub(r"//[^\n]*", "", body[body.index("{") + 1:body.index("};")])
+    fields = [f.strip() for decl in body.split(";") if decl.strip() for f in decl.strip()[4:].split(",")]
+    lib = C.CDLL(build.build_all()[0])
+    lib.sumo_debug_layout.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    want = {"RoboSumo-Ant-vs-Ant-v0": (8, 18, 29), "RoboSumo-Spider-vs-Spider-v0": (4, 40, 52)}
+    for env_id in ("RoboSumo-Ant-vs-Ant-v0", "RoboSumo-Bug-vs-Bug-v0", "RoboSumo-Spider-vs-Spider-v0", "RoboSumo-Ant-vs-Spider-v0"):
+        blob = mjcf.load_model(env_id).to_blob()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        out = (C.c_int32 * 256)()
+        n = lib.sumo_debug_layout(C.cast(buf, C.c_void_p), len(blob), out, 256)
+        assert n == len(fields)
+        L = dict(zip(fields, [int(out[i]) for i in range(n)]))
+        slots = 160 * 1024 // L["total_bytes"]
+        granules = -(-L["total_bytes"] // 1280)
+        assert slots >= 4 and slots * granules * 1280 <= 160 * 1024, (env_id, L["total_bytes"], slots)
+        assert L["maxcon"] <= L["jbcap"] <= 2 * L["maxcon"], (env_id, L["maxcon"], L["jbcap"])
+        spare = 160 * 1024 // slots // 1280 * 1280 - L["total_bytes"]
+        assert 0 <= spare < 192 or L["jbcap"] == 2 * L["maxcon"], (env_id, spare)       # no room for another half (192 B) is left unused
+        if env_id in want:
+            assert (slots, L["maxcon"], L["jbcap"]) == want[env_id], (env_id, slots, L["maxcon"], L["jbcap"])
