@@ -866,17 +866,29 @@ __global__ void __launch_bounds__(512) ppo_lstm_seq_fwd_kernel(LstmSeqArgs a) {
   const float bi = a.b[j], bf = a.b[NH + j] + a.forget_bias, bo = a.b[2 * NH + j], bu = a.b[3 * NH + j];
   float c[4], keep[4];
   f32x4 z[4];
+  // (plain loads at clamped rows, masks applied where the values are consumed: with a select right behind each load the compiler
+  // predicates the loads one by one and waits after each -- 28 serial trips to memory per time step instead of a prefetch)
   auto load_z = [&](int t, f32x4 (&zz)[4], float (&kp)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = r0 + 4 * kq + r;
-      const bool ok = row < a.n;
-      kp[r] = (ok && a.mask) ? 1.0f - a.mask[(size_t)t * a.n + row] : 1.0f;
+      const int rowc = row < a.n ? row : a.n - 1;
+      kp[r] = a.mask ? a.mask[(size_t)t * a.n + rowc] : 0.0f;          // the done flag itself; 1 - flag in finish_z
 #pragma unroll
-      for (int g = 0; g < 4; g++) zz[g][r] = ok ? a.z0[((size_t)t * a.n + row) * 4 * NH + g * NH + j] : 0.0f;
+      for (int g = 0; g < 4; g++) zz[g][r] = a.z0[((size_t)t * a.n + rowc) * 4 * NH + g * NH + j];
+    }
+  };
+  auto finish_z = [&](f32x4 (&zz)[4], float (&kp)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const bool ok = r0 + 4 * kq + r < a.n;
+      kp[r] = ok ? 1.0f - kp[r] : 1.0f;
+#pragma unroll
+      for (int g = 0; g < 4; g++) zz[g][r] = ok ? zz[g][r] : 0.0f;
     }
   };
   load_z(0, z, keep);
+  finish_z(z, keep);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row = r0 + 4 * kq + r;
@@ -901,6 +913,7 @@ __global__ void __launch_bounds__(512) ppo_lstm_seq_fwd_kernel(LstmSeqArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; g++) z[g] = MFMA(av, W[s_][g], z[g]);
     }
+    if (t + 1 < a.T) finish_z(zn, keepn);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = r0 + 4 * kq + r;
@@ -1044,15 +1057,22 @@ struct WgradArgs {
   float* slabs;                                                // [chunks][Mpad][Npad]
 };
 
-__device__ __forceinline__ void wgrad_col(const float* const* ptr, const int* ld, const int* cols, int nseg, int ones, int col,
+// (the segment tables are kernel arguments: with the segment loop unrolled over a compile-time count they are read as scalars; a
+// run-time loop indexed them per lane through memory, two dependent vector loads per column before the first product)
+template <int NSEG>
+__device__ __forceinline__ void wgrad_col(const float* const (&ptr)[NSEG], const int (&ld)[NSEG], const int (&cols)[NSEG], int ones, int col,
                                           const float*& base, int& stride, float& cval) {
   base = nullptr; stride = 0; cval = 0.0f;
   int c = col;
-  for (int sgm = 0; sgm < nseg; sgm++) {
-    if (c < cols[sgm]) { if (ptr[sgm]) { base = ptr[sgm] + c; stride = ld[sgm]; } return; }
-    c -= cols[sgm];
+  bool done = false;
+#pragma unroll
+  for (int sgm = 0; sgm < NSEG; sgm++) {
+    const bool here = !done && c < cols[sgm];
+    if (here && ptr[sgm]) { base = ptr[sgm] + c; stride = ld[sgm]; }
+    if (!done && !here) c -= cols[sgm];
+    done = done || here;
   }
-  if (ones && c == 0) cval = 1.0f;
+  if (!done && ones && c == 0) cval = 1.0f;
 }
 
 template <int MT, int NT>
@@ -1063,31 +1083,60 @@ __global__ void __launch_bounds__(256) ppo_wgrad_kernel(WgradArgs a) {
   const float* ap[MT]; int as[MT]; float ac[MT];
   const float* bp[NT]; int bs[NT]; float bc[NT];
 #pragma unroll
-  for (int m = 0; m < MT; m++) wgrad_col(a.a_ptr, a.a_ld, a.a_cols, 2, a.a_ones, (mt0 + m) * 16 + i, ap[m], as[m], ac[m]);
+  for (int m = 0; m < MT; m++) wgrad_col<2>(a.a_ptr, a.a_ld, a.a_cols, a.a_ones, (mt0 + m) * 16 + i, ap[m], as[m], ac[m]);
 #pragma unroll
-  for (int n = 0; n < NT; n++) wgrad_col(a.b_ptr, a.b_ld, a.b_cols, 3, 0, (nt0 + n) * 16 + i, bp[n], bs[n], bc[n]);
+  for (int n = 0; n < NT; n++) wgrad_col<3>(a.b_ptr, a.b_ld, a.b_cols, 0, (nt0 + n) * 16 + i, bp[n], bs[n], bc[n]);
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; m++)
 #pragma unroll
     for (int n = 0; n < NT; n++) acc[m][n] = (f32x4){0, 0, 0, 0};
-  for (int r0 = r_lo; r0 < r_hi; r0 += 8) {            // two k-steps (8 rows) per trip: their operand loads are in flight together
-    float av[2][MT], bv[2][NT];
+  // operand columns that are constants (bias ones, padding) read a valid dummy address with stride 0: every load of a trip is a plain
+  // unconditional load at a clamped row and the selects come afterwards -- with `ok ? p[row] : 0` the compiler predicated the loads
+  // one by one and waited after each (all 24 loads of a trip serial; tools: the serialized-load count of the disassembly)
+  const float PT_GAS* apx[MT]; const float PT_GAS* bpx[NT];   // (global address space: plain global loads, not flat ones)
+#pragma unroll
+  for (int m = 0; m < MT; m++) { apx[m] = pt_global(ap[m] ? ap[m] : a.slabs); if (!ap[m]) as[m] = 0; }   // (any readable address: the value is discarded)
+#pragma unroll
+  for (int n = 0; n < NT; n++) { bpx[n] = pt_global(bp[n] ? bp[n] : a.slabs); if (!bp[n]) bs[n] = 0; }
+  // two k-steps (8 rows) per trip; the NEXT trip's 2 (MT + NT) operand loads are issued before this trip's products (double-buffered)
+  float av[2][2][MT], bv[2][2][NT];
+  auto load_trip = [&](int buf, int r0) {
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int row = r0 + 4 * u + kq;
-      const bool ok = row < r_hi;
+      const int rowc = row < r_hi ? row : r_hi - 1;
 #pragma unroll
-      for (int m = 0; m < MT; m++) av[u][m] = ok ? (ap[m] ? ap[m][(size_t)row * as[m]] : ac[m]) : 0.0f;
+      for (int m = 0; m < MT; m++) av[buf][u][m] = apx[m][(size_t)rowc * as[m]];
 #pragma unroll
-      for (int n = 0; n < NT; n++) bv[u][n] = ok ? (bp[n] ? bp[n][(size_t)row * bs[n]] : bc[n]) : 0.0f;
+      for (int n = 0; n < NT; n++) bv[buf][u][n] = bpx[n][(size_t)rowc * bs[n]];
     }
+  };
+  auto trip = [&](int buf, int r0) {
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int u = 0; u < 2; u++) {
+      const bool ok = r0 + 4 * u + kq < r_hi;
+      float x[MT], y[NT];
+#pragma unroll
+      for (int m = 0; m < MT; m++) x[m] = ok ? (ap[m] ? av[buf][u][m] : ac[m]) : 0.0f;
+#pragma unroll
+      for (int n = 0; n < NT; n++) y[n] = ok ? (bp[n] ? bv[buf][u][n] : bc[n]) : 0.0f;
 #pragma unroll
       for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int n = 0; n < NT; n++) acc[m][n] = MFMA(av[u][m], bv[u][n], acc[m][n]);
+        for (int n = 0; n < NT; n++) acc[m][n] = MFMA(x[m], y[n], acc[m][n]);
+    }
+  };
+  if (r_lo < r_hi) load_trip(0, r_lo);
+  for (int r0 = r_lo; r0 < r_hi; r0 += 16) {     // (two trips per loop iteration so that the buffer index is a literal: registers, not scratch)
+    if (r0 + 8 < r_hi) load_trip(1, r0 + 8);
+    __builtin_amdgcn_sched_barrier(0);           // loads first: the scheduler otherwise sinks each load to its use and waits there
+    trip(0, r0);
+    if (r0 + 8 < r_hi) {
+      if (r0 + 16 < r_hi) load_trip(0, r0 + 16);
+      __builtin_amdgcn_sched_barrier(0);
+      trip(1, r0 + 8);
+    }
   }
   // D layout: lane (i, kq) holds rows 4 kq + r (A' column index within the tile), column i (B column within the tile)
   float* slab = a.slabs + (size_t)blockIdx.x * a.Mpad * a.Npad;
