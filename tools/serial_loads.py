@@ -4,7 +4,8 @@ with at most two operations in flight)?  Such loads are serial trips to memory; 
 select right behind a load makes the compiler predicate the load and wait inside the predicated block -- and per-lane indexing of small tables
 in kernel arguments.  Fixes that worked: load unconditionally at a clamped index and select afterwards; unroll table lookups over compile-time
 counts; `__builtin_amdgcn_sched_barrier(0)` after a block of loads that the scheduler sinks to their uses (ppo_grad_kernel 66 -> 48 us per call,
-ppo_wgrad_kernel 156 -> 63 us, ppo_lstm_seq_fwd_kernel 970 -> 863 us).  Static count: weigh it by how often the code runs.
+ppo_wgrad_kernel 156 -> 63 us, ppo_lstm_seq_fwd_kernel 970 -> 863 us).  Static count: weigh it by how often the code runs, and note that the LAST one or two loads of a
+properly pipelined batch (vmcnt 2, 1, 0) are counted as well -- look at the disassembly before acting on a number.
 usage: serial_loads.py lib.so [kernel-name-substring ...]"""
 import os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
