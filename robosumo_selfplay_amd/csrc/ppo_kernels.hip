@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(64 * NW) ppo_lstm_step_kernel(LstmArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; g++)
 #pragma unroll
-          for (int u = 0; u < UTW; u++) b[q][g * UTW + u] = ok ? wrow[(g * UT + wid * UTW + u) * 16 + i] : 0.0f;
+          for (int u = 0; u < UTW; u++) { const float wv = wrow[(g * UT + wid * UTW + u) * 16 + i]; b[q][g * UTW + u] = ok ? wv : 0.0f; }   // (a plain load from the clamped row, then the select: `ok ? load : 0` is a predicated load with its own wait)
       } else if (s_ < nsteps) {
         const int k = 4 * (s_ - xsteps) + kq;
         const float PT_GAS* wrow = gwh + (size_t)k * 4 * NH;
@@ -367,8 +367,11 @@ __global__ void __launch_bounds__(64 * NW) ppo_lstm_step_kernel(LstmArgs a) {
     for (int u = 0; u < 8; u++) {
       const int e = e0 + NT * u + tid, r = e / NH, k = e - r * NH, row = r0 + r;
       const bool in = e < 16 * NH && row < a.n;
-      v[u] = in ? a.h[(size_t)row * a.state_stride + k] : 0.0f;
-      keep[u] = (a.mask && in) ? 1.0f - a.mask[row] : 1.0f;
+      const int rowc = row < a.n ? row : a.n - 1, kc = k < NH ? k : 0;     // plain loads at clamped indices, selects afterwards
+      const float hv = a.h[(size_t)rowc * a.state_stride + kc];
+      const float mv = a.mask ? a.mask[rowc] : 0.0f;
+      v[u] = in ? hv : 0.0f;
+      keep[u] = in ? 1.0f - mv : 1.0f;
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -531,7 +534,7 @@ __global__ void __launch_bounds__(256) ppo_lstm_xproj_kernel(ppo_lstm_net N, con
 #pragma unroll
     for (int g = 0; g < 4; g++)
 #pragma unroll
-      for (int u = 0; u < UTW; u++) b[g * UTW + u] = ok ? wrow[(g * UT + wid * UTW + u) * 16 + i] : 0.0f;
+      for (int u = 0; u < UTW; u++) { const float wv = wrow[(g * UT + wid * UTW + u) * 16 + i]; b[g * UTW + u] = ok ? wv : 0.0f; }
   };
   float a0 = 0.0f, a1 = 0.0f, b0[NTW], b1[NTW];
   fetch(0, a0, b0);
