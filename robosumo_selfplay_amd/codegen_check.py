@@ -52,29 +52,30 @@ def kernels(asm):
         yield cur, body
 
 
+_BREAK = ("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc", "s_and_saveexec_b64", "s_or_saveexec_b64")
+
+
 def regions(body):
     """Yields (first, last) instruction indices of the bodies of branch-free predicated regions `s_and_saveexec_b64 sX, .. ; ... ; s_or_b64 exec, exec, sX`."""
-    i, n = 0, len(body)
-    while i < n:
-        m = re.match(r"s_and_saveexec_b64 (s\[\d+:\d+\]), ", body[i])
-        if not m:
-            i += 1
+    n = len(body)
+    nxt = 0
+    for i, t in enumerate(body):
+        if i < nxt or not t.startswith("s_and_saveexec_b64 "):
             continue
-        save = m.group(1)
+        save = t[len("s_and_saveexec_b64 "):].split(",", 1)[0].strip()
+        close = "s_or_b64 exec, exec, " + save
         j, ok = i + 1, False
         while j < n and j < i + 200:
-            t = body[j]
-            if t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")) or re.match(r"s_and_saveexec_b64|s_or_saveexec_b64", t):
+            u = body[j]
+            if u.startswith(_BREAK):
                 break
-            if t.startswith("s_or_b64 exec, exec, " + save):
+            if u.startswith(close):
                 ok = True
                 break
             j += 1
         if ok:
             yield i + 1, j
-            i = j + 1
-        else:
-            i += 1
+            nxt = j + 1
 
 
 def check(body):
@@ -100,26 +101,33 @@ def check_spills(body):
     return [(k, body[k]) for a, b in regions(body) for k in range(a, b) if body[k].startswith("scratch_store")]
 
 
+_STORES = ("ds_write", "global_store", "scratch_store", "flat_store", "buffer_store", "global_atomic", "ds_add")
+_NO_VDST = ("s_", "v_cmp", "v_cmpx")
+
+
 def scan_kernel(body):
     """-> [(instruction index, text, reads)] of suspicious copies in one kernel's instruction list."""
+    cands = check(body)
     out = []
-    for idx, t in check(body):
-        dst = int(re.search(r"v\[?(\d+)", t).group(1))
-        writes = reads = 0
+    if cands:
+        writes, reads = {}, {}                      # per VGPR: instructions that write / read it (one pass over the kernel)
         for u in body:
-            if " " not in u:
+            if " " not in u or "v" not in u:
                 continue
             op, rest = u.split(None, 1)
             ops = rest.split(",")
-            stores = op.startswith(("ds_write", "global_store", "scratch_store", "flat_store", "buffer_store", "global_atomic", "ds_add"))
-            if not stores and not op.startswith(("s_", "v_cmp", "v_cmpx")) and dst in vregs(ops[0]):
-                writes += 1
-                if len(ops) > 1 and dst in vregs(",".join(ops[1:])):
-                    reads += 1
-            elif dst in vregs(rest):
-                reads += 1
-        if writes == 1 and reads >= 1:
-            out.append((idx, t, reads))
+            if not op.startswith(_STORES) and not op.startswith(_NO_VDST):
+                for r in vregs(ops[0]):
+                    writes[r] = writes.get(r, 0) + 1
+                src = ",".join(ops[1:])
+            else:
+                src = rest
+            for r in vregs(src):
+                reads[r] = reads.get(r, 0) + 1
+        for idx, t in cands:
+            dst = int(re.search(r"v\[?(\d+)", t).group(1))
+            if writes.get(dst, 0) == 1 and reads.get(dst, 0) >= 1:
+                out.append((idx, t, reads[dst]))
     out += [(idx, t, 0) for idx, t in check_spills(body)]
     return out
 
