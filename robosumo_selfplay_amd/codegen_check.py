@@ -95,6 +95,21 @@ def check(body):
     return bad
 
 
+def check_before_endcf(body):
+    """-> list of (index, text): register moves that sit directly in front of an `s_or_b64 exec, exec, sX` (the END_CF at the top of a join
+    block) -- the placement itself, whether or not the predicated region in front of it still has its skip branch."""
+    bad = []
+    for j, t in enumerate(body):
+        if not t.startswith("s_or_b64 exec, exec, "):
+            continue
+        k = j - 1
+        while k >= 0 and j - k <= 8 and body[k].startswith(("v_mov_b32_e32", "v_mov_b64_e32", "s_mov_b32", "s_mov_b64", "s_nop")):
+            if body[k].startswith("v_mov"):
+                bad.append((k, body[k]))
+            k -= 1
+    return bad
+
+
 def check_spills(body):
     """-> list of (index, text): VGPR spill stores inside such a region (the same placement through the scratch frame: only the region's
     lanes reach the slot).  The shipped kernels have none."""
@@ -108,6 +123,8 @@ _NO_VDST = ("s_", "v_cmp", "v_cmpx")
 def scan_kernel(body):
     """-> [(instruction index, text, reads)] of suspicious copies in one kernel's instruction list."""
     cands = check(body)
+    seen = {i for i, _ in cands}
+    cands += [(i, t) for i, t in check_before_endcf(body) if i not in seen]
     out = []
     if cands:
         writes, reads = {}, {}                      # per VGPR: instructions that write / read it (one pass over the kernel)
