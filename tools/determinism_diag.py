@@ -9,7 +9,7 @@ from robosumo_selfplay_amd.vec_env import SumoVecEnv
 env_id = sys.argv[1] if len(sys.argv) > 1 else "RoboSumo-Ant-vs-Ant-v0"
 reps, T, N = int(sys.argv[2]) if len(sys.argv) > 2 else 6, 6, 4096
 m = mjcf.load_model(env_id)
-A = int(m.act_dims[0])
+A = int(max(m.act_dims))          # the action tensor has the wider agent's width (act_stride)
 g = torch.Generator(device="cpu").manual_seed(0)
 acts = torch.randn((T, N, 2, A), generator=g).to("cuda")
 ref = None
