@@ -207,8 +207,8 @@ class Engine:
         return dict(aborted=int(o[0]), tickets_drawn=int(o[1]), tickets=int(o[2]), mismatches=int(o[3]))
 
     def static_layout(self):
-        """True if this engine runs the static-Layout kernel variants (flagship scene, default settings; include/sumo_hip.h)."""
-        return lib().sumo_static_layout(self.h) == 1
+        """True if this engine runs static-Layout kernel variants (Ant-vs-Ant or Spider-vs-Spider at default settings; include/sumo_hip.h)."""
+        return lib().sumo_static_layout(self.h) >= 1
 
     def debug_fault(self, env):
         """Tests: make the first hand-over of ``env`` in the following fused launches carry a wrong checksum (-1 = off)."""

@@ -488,12 +488,12 @@ struct Ctx {
 template <class C>
 __device__ __forceinline__ decltype(auto) model_view(const C& c) {
   if constexpr (std::is_same<typename C::LT, Layout>::value) return (const sumo_model_t&)c.P->mdl;
-  else { ModelAntAnt m; m.ibase = c.P->mdl.ibase; m.fbase = c.P->mdl.fbase; m.tatami_size = c.P->mdl.tatami_size; return m; }
+  else { typename C::LT::Model m; m.ibase = c.P->mdl.ibase; m.fbase = c.P->mdl.fbase; m.tatami_size = c.P->mdl.tatami_size; return m; }
 }
 template <class C>
 __device__ __forceinline__ decltype(auto) aux_view(const C& c) {
   if constexpr (std::is_same<typename C::LT, Layout>::value) return (const Aux&)c.P->aux;
-  else { AuxAntAnt x; x.ai = c.P->aux.ai; x.af = c.P->aux.af; x.pic = c.P->aux.pic; return x; }
+  else { typename C::LT::AuxT x; x.ai = c.P->aux.ai; x.af = c.P->aux.af; x.pic = c.P->aux.pic; return x; }
 }
 #define S(off) (c.sm + c.L.off)
 // Per-lane constants are re-read at the start of each phase instead of being pinned in registers for the whole launch
@@ -2408,6 +2408,7 @@ __device__ __forceinline__ void env_step_body(C& c, const SA& a, int e) {
 
 template <int SL> struct LayoutSel { typedef Layout type; };
 template <> struct LayoutSel<1> { typedef LayoutAntAnt type; };
+template <> struct LayoutSel<2> { typedef LayoutSpiderSpider type; };
 
 template <int NV, int SL = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(SUMO_WPE_OF(NV), SUMO_WPE_OF(NV)))) sumo_step_kernel(const Params* P, StepArgs a) {
@@ -2947,7 +2948,7 @@ struct sumo_engine {
   long long rollout_tickets = -1;          // N * K of the most recent fused launch, -1: none yet
   int dbg_fault_env = -1;                  // sumo_debug_fault
   double* dbg_dump = nullptr;              // sumo_debug_dump (SUMO_DBG_DUMP builds)
-  int static_layout = 0;                   // 1: the scene's Layout equals the compile-time table (LayoutAntAnt): static kernel variants
+  int static_layout = 0;                   // 1 / 2: the scene's Layout equals a compile-time table (Ant-vs-Ant / Spider-vs-Spider): static kernel variants
   unsigned long long acked_faults = 0;     // stats[9] + stats[10] already reported by sumo_rollout_status
   long long sched_t = 0;                                                                     // step launches so far (in-kernel ranking)
   void* d_sort_tmp = nullptr;
@@ -3419,10 +3420,16 @@ extern "C" int sumo_create(const void* model_blob, size_t nbytes, int num_envs, 
     const char* sl = getenv("SUMO_STATIC_LAYOUT");
     int32_t mi[160];
     const int nmi = model_ints(&E->hm, mi);
-    E->static_layout = sizeof(kLayoutAntAnt) == sizeof(Layout) && memcmp(&E->L, kLayoutAntAnt, sizeof(Layout)) == 0 &&
-                       sizeof(kModelAntAnt) == nmi * sizeof(int) && memcmp(mi, kModelAntAnt, sizeof(kModelAntAnt)) == 0 &&
-                       sizeof(kAuxAntAnt) == AUX_NINTS * sizeof(int) && memcmp(&E->aux.ndepth, kAuxAntAnt, sizeof(kAuxAntAnt)) == 0 &&
-                       !(sl && atoi(sl) == 0);
+    auto same = [&](const int* kl, size_t nl, const int* km, size_t nm_, const int* ka, size_t na) {
+      return nl == sizeof(Layout) && memcmp(&E->L, kl, nl) == 0 && nm_ == nmi * sizeof(int) && memcmp(mi, km, nm_) == 0 &&
+             na == AUX_NINTS * sizeof(int) && memcmp(&E->aux.ndepth, ka, na) == 0;
+    };
+    E->static_layout = 0;      // 1: Ant-vs-Ant, 2: Spider-vs-Spider (the scenes of csrc/layout_static.h), 0: runtime-Layout variants
+    if (!(sl && atoi(sl) == 0)) {
+      if (same(kLayoutAntAnt, sizeof(kLayoutAntAnt), kModelAntAnt, sizeof(kModelAntAnt), kAuxAntAnt, sizeof(kAuxAntAnt))) E->static_layout = 1;
+      else if (same(kLayoutSpiderSpider, sizeof(kLayoutSpiderSpider), kModelSpiderSpider, sizeof(kModelSpiderSpider), kAuxSpiderSpider, sizeof(kAuxSpiderSpider)))
+        E->static_layout = 2;
+    }
   }
   if (E->L.maxefc > WAVE * (E->hm.nv <= 28 ? 2 : 4)) { int me = E->L.maxefc; delete E; FAIL(-24, "maxefc %d exceeds the rows a lane keeps in registers", me); }
   hipDeviceProp_t prop;
@@ -3604,9 +3611,12 @@ extern "C" int sumo_step(sumo_handle_t E, const float* actions_dev, float* obs_d
   }
   if (E->cfrc_mode)   // rne_post: the state this step starts from, for the second launch below
     HIPCHK(hipMemcpyAsync(E->d_state_prev, E->d_state, (size_t)E->N * E->state_stride * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  if (E->static_layout && E->hm.nv == 28) {
+  if (E->static_layout == 1) {
     dim3 g_(nblocks), b_(WAVE);
     hipLaunchKernelGGL((sumo_step_kernel<28, 1>), g_, b_, (size_t)E->L.total_bytes, (hipStream_t)stream, E->d_params, a);
+  } else if (E->static_layout == 2) {
+    dim3 g_(nblocks), b_(WAVE);
+    hipLaunchKernelGGL((sumo_step_kernel<44, 2>), g_, b_, (size_t)E->L.total_bytes, (hipStream_t)stream, E->d_params, a);
   } else
     SUMO_DISPATCH_N(sumo_step_kernel, E, (hipStream_t)stream, a, nblocks);
   HIPCHK(hipGetLastError());
@@ -3665,9 +3675,12 @@ static int rollout_launch(sumo_engine* E, const RolloutArgs& r, int policy, floa
   if (nw > (long long)E->N) nw = E->N;   // more waves than envs would only wait on each other's steps
   dim3 g_((unsigned)nw), b_(WAVE);
   size_t lds_ = (size_t)E->L.total_bytes;
-  if (E->static_layout && E->hm.nv == 28) {
+  if (E->static_layout == 1) {
     if (policy == 1) hipLaunchKernelGGL((sumo_rollout_kernel<28, 1, 1>), g_, b_, lds_, st_, E->d_params, rl);
     else hipLaunchKernelGGL((sumo_rollout_kernel<28, 0, 1>), g_, b_, lds_, st_, E->d_params, rl);
+  } else if (E->static_layout == 2) {
+    if (policy == 1) hipLaunchKernelGGL((sumo_rollout_kernel<44, 1, 2>), g_, b_, lds_, st_, E->d_params, rl);
+    else hipLaunchKernelGGL((sumo_rollout_kernel<44, 0, 2>), g_, b_, lds_, st_, E->d_params, rl);
   } else if (!for_kernel_variant(E->hm.nv, [&](auto nvc_) {
         if (policy == 1) hipLaunchKernelGGL((sumo_rollout_kernel<decltype(nvc_)::value, 1>), g_, b_, lds_, st_, E->d_params, rl);
         else hipLaunchKernelGGL((sumo_rollout_kernel<decltype(nvc_)::value, 0>), g_, b_, lds_, st_, E->d_params, rl);

@@ -188,33 +188,35 @@ def test_batch_independence_and_determinism(env_id):
     assert st["diverged"] == 0
 
 
-def test_static_layout_variants_match_runtime_layout(monkeypatch):
-    """The flagship scene runs kernel variants whose LDS layout / model dimensions / table offsets are compile-time constants
+@pytest.mark.parametrize("env_id,tol", [("RoboSumo-Ant-vs-Ant-v0", 1e-9), ("RoboSumo-Spider-vs-Spider-v0", 1e-7)])
+def test_static_layout_variants_match_runtime_layout(monkeypatch, env_id, tol):
+    """Ant-vs-Ant and Spider-vs-Spider run kernel variants whose LDS layout / model dimensions / table offsets are compile-time constants
     (csrc/layout_static.h); every other scene, and SUMO_STATIC_LAYOUT=0, the runtime-Layout variants.  The two are different
     compilations of the same source (literals change which multiply-add pairs the compiler contracts), so they agree to float64
-    rounding, not bit for bit: float32 observations equal, float64 states / rewards to 1e-9 after 12 free-running steps -- both
-    sit inside the 1e-9-per-step band of the oracle parity tests, which run on the static variants."""
+    rounding, not bit for bit: float32 observations equal to 1e-6, float64 states / rewards to `tol` after 12 free-running steps -- both
+    sit inside the per-step band of the oracle parity tests, which run on the static variants."""
     outs = {}
+    A = int(max(mjcf.load_model(env_id).act_dims))
     for flag in ("1", "0"):
         monkeypatch.setenv("SUMO_STATIC_LAYOUT", flag)
-        env = SumoVecEnv("RoboSumo-Ant-vs-Ant-v0", num_envs=96, seed=7)
+        env = SumoVecEnv(env_id, num_envs=96, seed=7)
         assert env.engine.static_layout() == (flag == "1")
         env.reset_device()
         g = torch.Generator(device="cpu").manual_seed(0)
-        acts = torch.randn((12, 96, 2, 8), generator=g).to("cuda") * 1.5
+        acts = torch.randn((12, 96, 2, A), generator=g).to("cuda") * 1.5
         for t in range(12):
             obs, info, done, *_ = env.step_device(acts[t].contiguous())
         torch.cuda.synchronize()
         outs[flag] = (obs.cpu().numpy().copy(), info.cpu().numpy().copy(), env.engine.get_state(), env.stats())
         env.close()
-    assert np.abs(outs["1"][0] - outs["0"][0]).max() < 1e-6 and np.allclose(outs["1"][1], outs["0"][1], rtol=1e-9, atol=1e-9)
+    assert np.abs(outs["1"][0] - outs["0"][0]).max() < max(1e-6, 10 * tol) and np.allclose(outs["1"][1], outs["0"][1], rtol=tol, atol=tol)
     for x, y in zip(outs["1"][2][:3], outs["0"][2][:3]):
-        assert np.allclose(x, y, rtol=1e-9, atol=1e-9)
+        assert np.allclose(x, y, rtol=tol, atol=tol)
     assert np.array_equal(outs["1"][2][3], outs["0"][2][3])            # step / reset counters
     for k in ("forward", "newton", "contacts", "efc"):
         assert outs["1"][3][k] == outs["0"][3][k]
     monkeypatch.delenv("SUMO_STATIC_LAYOUT")
-    env = SumoVecEnv("RoboSumo-Spider-vs-Spider-v0", num_envs=4, seed=1)
+    env = SumoVecEnv("RoboSumo-Bug-vs-Bug-v0", num_envs=4, seed=1)
     assert not env.engine.static_layout()
     env.close()
 
