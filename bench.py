@@ -555,6 +555,14 @@ def main():
             out["config"]["spider"] = spider
         if recurrent is not None:
             out["config"]["recurrent"] = recurrent
+        # static scan of the code objects this run loaded for the register-allocator defect of DESIGN.md section 4 ("code-generation
+        # hazard"): suspicious copies per library (0 = clean), None if the tools are missing
+        try:
+            from robosumo_selfplay_amd import build as _build, codegen_check as _cc
+            out["config"]["codegen_check"] = {name: sum(len(v) for v in _cc.scan_library(_build.lib_path(name)).values())
+                                              for name in ("libsumo_hip.so", "libsumo_ppo.so")}
+        except Exception:
+            out["config"]["codegen_check"] = None
         out["host"] = {"cpu_model": hostcfg.cpu_model(), "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": hostcfg.cpu_quota(),
                        "pool_threads": hostcfg.apply(),
                        "throttled_periods_in_timed_region": None if thr0 is None or thr1 is None else thr1[0] - thr0[0]}
